@@ -1,0 +1,469 @@
+// Paged attention for gfx950 (CDNA4): MFMA flash-attention over a paged bf16 KV cache.
+//
+// Cache page layout (see common.h): per layer and page, K is [kv_head][64 keys][128 ch]
+// and V is stored TRANSPOSED, [kv_head][128 ch][64 keys].  With that layout both matrix
+// products take their A operand with plain 16-byte reads:
+//   S^T[key, q] = K[key, :] . Q[q, :]        A = K rows   (8 contiguous channels / lane)
+//   O^T[ch,  q] = V^T[ch, :] . P^T[:, q]     A = V^T rows (8 contiguous keys / lane)
+// and the S^T accumulator of the first product IS the B operand of the second (the
+// query sits on the lane in both), so the probabilities never leave registers.
+// Because the MFMA accumulator interleaves rows between the two half-waves, the K rows
+// are fed to the first product in a permuted order chosen so that accumulator register
+// (8s + j) of half-wave h holds key 16s + 8h + j: exactly the k-order of a natural
+// 16-byte V^T read.
+//
+// Prefill kernel: one workgroup = 4 waves sharing one KV head's K/V stream through LDS
+// (XOR-swizzled, conflict-free for ds_read_b128); each wave owns 32 query rows of one
+// query head.  Tiles of 64 keys (= one page) are register-staged: the global loads of
+// tile t+1 are issued before the MFMA work on tile t and written to LDS after it.
+//
+// Decode kernel: one query token per sequence; K/V go straight from HBM to registers
+// (no reuse across waves, so LDS staging would only add a round trip); the GQA group's
+// query heads occupy the columns of a 16x16x32 MFMA so each K/V byte is read once for
+// the whole group.  Context is split across the 4 waves of a workgroup and across
+// `num_splits` workgroups; a small second kernel merges the split partials.
+#include "common.h"
+
+#define NEG_BIG (-1.0e30f)
+
+__device__ __forceinline__ bf16x8 lds_read_frag(const char* lds, int byte_off) {
+  return *reinterpret_cast<const bf16x8*>(lds + byte_off);
+}
+
+// ---------------------------------------------------------------------------------
+// Prefill / chunked prefill / prefix-hit prefill.
+//   q, out       [tokens, n_q * 128] bf16 with explicit row strides
+//   tile_seq[i], tile_q0[i]: work list, one entry per (sequence, query tile of QT rows)
+//   cu_q[s]      first row of sequence s in q/out; q_len = cu_q[s+1] - cu_q[s]
+//   ctx_lens[s]  keys visible to the LAST query row of s (cached prefix + new tokens; the
+//                new tokens' K/V are already in the cache when this kernel runs)
+// grid = (num_tiles, n_kv * max(G/4, 1)); block = 256.
+// GP = min(G, 4) query heads share a workgroup; QT = 32 * (4 / GP) query rows per tile.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
+    const uint16_t* __restrict__ q, long q_stride, uint16_t* __restrict__ out, long out_stride,
+    const uint16_t* __restrict__ cache, long page_stride, long v_offset,
+    const int* __restrict__ block_tables, int max_blocks, const int* __restrict__ cu_q,
+    const int* __restrict__ ctx_lens, const int* __restrict__ tile_seq,
+    const int* __restrict__ tile_q0, int n_q, int n_kv, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* lds_k = lds;           // 64 keys x 256 B
+  char* lds_v = lds + 16384;   // 128 channels x 128 B
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31;
+  const int h = lane >> 5;
+
+  const int G = n_q / n_kv;
+  const int GP = G < 4 ? G : 4;
+  const int groups_per_kv = G / GP;
+  const int kvh = blockIdx.y / groups_per_kv;
+  const int hg = blockIdx.y % groups_per_kv;
+  const int head = kvh * G + hg * GP + (wave % GP);
+  const int qsub = wave / GP;
+
+  const int seq = tile_seq[blockIdx.x];
+  const int q0 = tile_q0[blockIdx.x];
+  const int row0 = cu_q[seq];
+  const int q_len = cu_q[seq + 1] - row0;
+  const int ctx = ctx_lens[seq];
+  const int pos0 = ctx - q_len;  // absolute position of the sequence's first new token
+  const int QT = 32 * (4 / GP);
+
+  // rows of this wave / block
+  const int wq0 = q0 + qsub * 32;
+  const int my_row = wq0 + r;
+  const bool row_ok = my_row < q_len;
+  const int my_pos = row_ok ? pos0 + my_row : ctx - 1;
+  int w_last = wq0 + 31;
+  if (w_last > q_len - 1) w_last = q_len - 1;
+  const bool wave_ok = wq0 < q_len;
+  const int w_max_pos = pos0 + w_last;   // last key this wave needs
+  const int w_min_pos = pos0 + wq0;      // first row's position
+  int b_last = q0 + QT - 1;
+  if (b_last > q_len - 1) b_last = q_len - 1;
+  const int n_tiles = (pos0 + b_last) / PAGE + 1;
+
+  // ---- Q fragments (B operand): lane holds Q[row r][16*ks + 8h .. +8]
+  bf16x8 qf[8];
+  {
+    const uint16_t* qp = q + (long)(row0 + (row_ok ? my_row : 0)) * q_stride + head * HEAD_DIM + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + 16 * ks);
+      if (!row_ok) v = (u32x4){0, 0, 0, 0};
+      qf[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+
+  const int* bt = block_tables + (long)seq * max_blocks;
+
+  // staging registers: 4 K chunks + 4 V chunks of 16 B per thread
+  u32x4 sk[4], sv[4];
+  auto stage_load = [&](int tile) {
+    const long page = bt[tile];
+    const uint16_t* kp = cache + page * page_stride + (long)kvh * PAGE * HEAD_DIM;
+    const uint16_t* vp = cache + page * page_stride + v_offset + (long)kvh * HEAD_DIM * PAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = i * 256 + tid;
+      sk[i] = *reinterpret_cast<const u32x4*>(kp + id * 8);
+      sv[i] = *reinterpret_cast<const u32x4*>(vp + id * 8);
+    }
+  };
+  auto stage_write = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = i * 256 + tid;
+      const int key = id >> 4, c = id & 15;
+      *reinterpret_cast<u32x4*>(lds_k + key * 256 + ((c ^ (key & 15)) << 4)) = sk[i];
+      const int d = id >> 3, cv = id & 7;
+      *reinterpret_cast<u32x4*>(lds_v + d * 128 + ((cv ^ ((d >> 1) & 7)) << 4)) = sv[i];
+    }
+  };
+
+  f32x16 o_acc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o_acc[dt][i] = 0.f;
+  float m_run = NEG_BIG;
+  float l_run = 0.f;
+
+  // MFMA row rho of a 32-key half-tile reads key swap_bits23(rho)
+  const int krow = (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1);
+
+  stage_load(0);
+  stage_write();
+  __syncthreads();
+
+  for (int t = 0; t < n_tiles; ++t) {
+    if (t + 1 < n_tiles) stage_load(t + 1);
+
+    const int kbase = t * PAGE;
+    if (wave_ok && kbase <= w_max_pos) {
+      f32x16 s_acc[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s_acc[tt][i] = 0.f;
+        const int key = tt * 32 + krow;
+        const int rowoff = key * 256;
+        const int sw = key & 15;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          bf16x8 a = lds_read_frag(lds_k, rowoff + (((2 * ks + h) ^ sw) << 4));
+          s_acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s_acc[tt], 0, 0, 0);
+        }
+      }
+      // ---- online softmax (base-2 domain); accumulator reg i of half h = key
+      //      kbase + 32 tt + 16 (i>>3) + 8 h + (i&7)
+      const bool need_mask = (kbase + PAGE - 1) > w_min_pos;
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float v = s_acc[tt][i] * scale_log2e;
+          if (need_mask) {
+            const int key = kbase + 32 * tt + 16 * (i >> 3) + 8 * h + (i & 7);
+            if (key > my_pos) v = NEG_BIG;
+          }
+          s_acc[tt][i] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      float psum = 0.f;
+      bf16x8 pf[4];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          u32x4 pk;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const float p0 = __builtin_amdgcn_exp2f(s_acc[tt][8 * s + 2 * jj] - m_new);
+            const float p1 = __builtin_amdgcn_exp2f(s_acc[tt][8 * s + 2 * jj + 1] - m_new);
+            psum += p0 + p1;
+            pk[jj] = pack_bf16x2(p0, p1);
+          }
+          pf[tt * 2 + s] = __builtin_bit_cast(bf16x8, pk);
+        }
+      l_run = l_run * alpha + psum;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o_acc[dt][i] *= alpha;
+        const int d = 32 * dt + r;
+        const int rowoff = d * 128;
+        const int sw = (d >> 1) & 7;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          bf16x8 a = lds_read_frag(lds_v, rowoff + (((2 * kk + h) ^ sw) << 4));
+          o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[kk], o_acc[dt], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (t + 1 < n_tiles) stage_write();
+    __syncthreads();
+  }
+
+  // ---- epilogue: O^T accumulator reg i of half h, tile dt = channel 32dt + 8(i>>2) + 4h + (i&3)
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (row_ok) {
+    const float inv = 1.f / l_tot;
+    uint16_t* op = out + (long)(row0 + my_row) * out_stride + head * HEAD_DIM;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        u32x2 w;
+        w[0] = pack_bf16x2(o_acc[dt][4 * g4] * inv, o_acc[dt][4 * g4 + 1] * inv);
+        w[1] = pack_bf16x2(o_acc[dt][4 * g4 + 2] * inv, o_acc[dt][4 * g4 + 3] * inv);
+        *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g4 + 4 * h) = w;
+      }
+  }
+}
+
+VPSA_EXPORT int vpsa_paged_prefill(const void* q, long q_stride, void* out, long out_stride,
+                                   const void* cache, long page_stride, long v_offset,
+                                   const int* block_tables, int max_blocks, const int* cu_q,
+                                   const int* ctx_lens, const int* tile_seq, const int* tile_q0,
+                                   int num_tiles, int n_q, int n_kv, float scale,
+                                   hipStream_t stream) {
+  if (num_tiles <= 0) return 0;
+  if (n_q % n_kv != 0) return -1;
+  const int G = n_q / n_kv;
+  if (G > 4 && G % 4 != 0) return -1;
+  if (G == 3) return -1;
+  const int GP = G < 4 ? G : 4;
+  dim3 grid(num_tiles, n_kv * (G / GP)), block(256);
+  hipLaunchKernelGGL(paged_prefill_kernel, grid, block, 32768, stream, (const uint16_t*)q,
+                     q_stride, (uint16_t*)out, out_stride, (const uint16_t*)cache, page_stride,
+                     v_offset, block_tables, max_blocks, cu_q, ctx_lens, tile_seq, tile_q0, n_q,
+                     n_kv, scale * 1.4426950408889634f);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// Decode: one query token per sequence.
+//   q, out  [num_seqs, n_q * 128] bf16
+//   ws_o    [num_seqs, n_q, num_splits, 128] fp32 (unnormalised), ws_ml [.., 2] = (max, sum)
+// grid = (num_seqs, n_kv, num_splits); block = 256 (4 waves, interleaved over 32-key chunks).
+// Requires G = n_q / n_kv <= 16.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void paged_decode_kernel(
+    const uint16_t* __restrict__ q, long q_stride, uint16_t* __restrict__ out, long out_stride,
+    const uint16_t* __restrict__ cache, long page_stride, long v_offset,
+    const int* __restrict__ block_tables, int max_blocks, const int* __restrict__ ctx_lens,
+    float* __restrict__ ws_o, float* __restrict__ ws_ml, int n_q, int n_kv, int num_splits,
+    float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float* lds_o = reinterpret_cast<float*>(lds);               // [4][128][16]
+  float* lds_m = reinterpret_cast<float*>(lds + 32768);       // [4][16]
+  float* lds_l = reinterpret_cast<float*>(lds + 32768 + 256); // [4][16]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15;
+  const int g = lane >> 4;
+
+  const int seq = blockIdx.x;
+  const int kvh = blockIdx.y;
+  const int split = blockIdx.z;
+  const int G = n_q / n_kv;
+  const int ctx = ctx_lens[seq];
+
+  const int nchunks = (ctx + 31) >> 5;
+  const int per_split = (nchunks + num_splits - 1) / num_splits;
+  const int c_begin = split * per_split;
+  int c_end = c_begin + per_split;
+  if (c_end > nchunks) c_end = nchunks;
+
+  // Q fragments: B[k = 32 ks + 8 g + j][col = query head c16]
+  bf16x8 qf[4];
+  {
+    const bool ok = c16 < G;
+    const uint16_t* qp =
+        q + (long)seq * q_stride + (long)(kvh * G + (ok ? c16 : 0)) * HEAD_DIM + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + 32 * ks);
+      if (!ok) v = (u32x4){0, 0, 0, 0};
+      qf[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+
+  f32x4 o_acc[8];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) o_acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = NEG_BIG, l_run = 0.f;
+
+  const int* bt = block_tables + (long)seq * max_blocks;
+  // MFMA row rho = c16 of key sub-tile t reads key 8*(rho>>2) + 4t + (rho&3)
+  const int krow_base = 8 * (c16 >> 2) + (c16 & 3);
+
+  for (int c = c_begin + wave; c < c_end; c += 4) {
+    const long page = bt[c >> 1];
+    const int koff = (c & 1) * 32;
+    const uint16_t* kp = cache + page * page_stride + (long)kvh * PAGE * HEAD_DIM;
+    const uint16_t* vp = cache + page * page_stride + v_offset + (long)kvh * HEAD_DIM * PAGE;
+    u32x4 kf[2][4], vf[8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        kf[t][ks] = *reinterpret_cast<const u32x4*>(kp + (koff + krow_base + 4 * t) * HEAD_DIM +
+                                                    32 * ks + 8 * g);
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+      vf[dt] = *reinterpret_cast<const u32x4*>(vp + (16 * dt + c16) * PAGE + koff + 8 * g);
+
+    f32x4 s_acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      s_acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        s_acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[t][ks]),
+                                                           qf[ks], s_acc[t], 0, 0, 0);
+    }
+    // accumulator reg of sub-tile t, lane group g = key c*32 + 8g + 4t + reg
+    float mx = NEG_BIG;
+    const int key0 = c * 32 + 8 * g;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = s_acc[t][i] * scale_log2e;
+        if (key0 + 4 * t + i >= ctx) v = NEG_BIG;
+        s_acc[t][i] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    u32x4 pk;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        float p0 = __builtin_amdgcn_exp2f(s_acc[t][2 * jj] - m_new);
+        float p1 = __builtin_amdgcn_exp2f(s_acc[t][2 * jj + 1] - m_new);
+        // keys past the context contribute exactly zero even when the whole chunk is masked
+        if (key0 + 4 * t + 2 * jj >= ctx) p0 = 0.f;
+        if (key0 + 4 * t + 2 * jj + 1 >= ctx) p1 = 0.f;
+        psum += p0 + p1;
+        pk[t * 2 + jj] = pack_bf16x2(p0, p1);
+      }
+    l_run = l_run * alpha + psum;
+    const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      o_acc[dt] *= alpha;
+      o_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf[dt]), pf,
+                                                         o_acc[dt], 0, 0, 0);
+    }
+  }
+
+  // combine the four lane groups' partial sums, then the four waves through LDS
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lds_o[(wave * 128 + 16 * dt + 4 * g + i) * 16 + c16] = o_acc[dt][i];
+  if (g == 0) {
+    lds_m[wave * 16 + c16] = m_run;
+    lds_l[wave * 16 + c16] = l_run;
+  }
+  __syncthreads();
+
+  const int qh = tid & 15;
+  const int dgrp = tid >> 4;  // 16 groups of 8 channels
+  if (qh < G) {
+    float M = NEG_BIG;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) M = fmaxf(M, lds_m[w * 16 + qh]);
+    float L = 0.f;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = __builtin_amdgcn_exp2f(lds_m[w * 16 + qh] - M);
+      L += lds_l[w * 16 + qh] * f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += lds_o[(w * 128 + dgrp * 8 + k) * 16 + qh] * f;
+    }
+    const int head = kvh * G + qh;
+    if (num_splits == 1) {
+      const float inv = L > 0.f ? 1.f / L : 0.f;
+      u32x4 w4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w4[k] = pack_bf16x2(acc[2 * k] * inv, acc[2 * k + 1] * inv);
+      *reinterpret_cast<u32x4*>(out + (long)seq * out_stride + head * HEAD_DIM + dgrp * 8) = w4;
+    } else {
+      const long base = ((long)seq * n_q + head) * num_splits + split;
+      float* wo = ws_o + base * HEAD_DIM + dgrp * 8;
+      *reinterpret_cast<f32x4*>(wo) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+      *reinterpret_cast<f32x4*>(wo + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+      if (dgrp == 0) {
+        ws_ml[base * 2] = M;
+        ws_ml[base * 2 + 1] = L;
+      }
+    }
+  }
+}
+
+// merge split partials: grid = (num_seqs, n_q), block = 128 (one channel per thread)
+__global__ __launch_bounds__(128) void decode_reduce_kernel(const float* __restrict__ ws_o,
+                                                            const float* __restrict__ ws_ml,
+                                                            uint16_t* __restrict__ out,
+                                                            long out_stride, int n_q,
+                                                            int num_splits) {
+  const int seq = blockIdx.x, head = blockIdx.y, d = threadIdx.x;
+  const long base = ((long)seq * n_q + head) * num_splits;
+  float M = NEG_BIG;
+  for (int s = 0; s < num_splits; ++s) M = fmaxf(M, ws_ml[(base + s) * 2]);
+  float L = 0.f, acc = 0.f;
+  for (int s = 0; s < num_splits; ++s) {
+    const float f = __builtin_amdgcn_exp2f(ws_ml[(base + s) * 2] - M);
+    L += ws_ml[(base + s) * 2 + 1] * f;
+    acc += ws_o[(base + s) * HEAD_DIM + d] * f;
+  }
+  const float r = L > 0.f ? acc / L : 0.f;
+  bf16_t b = (bf16_t)r;
+  out[(long)seq * out_stride + head * HEAD_DIM + d] = __builtin_bit_cast(uint16_t, b);
+}
+
+VPSA_EXPORT int vpsa_paged_decode(const void* q, long q_stride, void* out, long out_stride,
+                                  const void* cache, long page_stride, long v_offset,
+                                  const int* block_tables, int max_blocks, const int* ctx_lens,
+                                  void* ws_o, void* ws_ml, int num_seqs, int n_q, int n_kv,
+                                  int num_splits, float scale, hipStream_t stream) {
+  if (num_seqs <= 0) return 0;
+  if (n_q % n_kv != 0 || n_q / n_kv > 16 || num_splits < 1) return -1;
+  if (num_splits > 1 && (!ws_o || !ws_ml)) return -1;
+  dim3 grid(num_seqs, n_kv, num_splits), block(256);
+  hipLaunchKernelGGL(paged_decode_kernel, grid, block, 32768 + 512, stream, (const uint16_t*)q,
+                     q_stride, (uint16_t*)out, out_stride, (const uint16_t*)cache, page_stride,
+                     v_offset, block_tables, max_blocks, ctx_lens, (float*)ws_o, (float*)ws_ml,
+                     n_q, n_kv, num_splits, scale * 1.4426950408889634f);
+  if (num_splits > 1) {
+    hipLaunchKernelGGL(decode_reduce_kernel, dim3(num_seqs, n_q), dim3(128), 0, stream,
+                       (const float*)ws_o, (const float*)ws_ml, (uint16_t*)out, out_stride, n_q,
+                       num_splits);
+  }
+  return 0;
+}

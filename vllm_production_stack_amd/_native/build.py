@@ -1,0 +1,97 @@
+"""Build every native library of the stack in-tree.
+
+HIP device code is compiled for gfx950 only (``hipcc --offload-arch=gfx950``; it
+cross-compiles without a GPU present); host-only C++ is built with g++.  The shared
+objects land next to this file so that they travel with the source tree and are loaded
+with ``ctypes`` (no Python C-API, no torch headers: a full rebuild takes seconds).
+
+Usage:  python -m vllm_production_stack_amd._native.build [--force] [target ...]
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+CSRC = ROOT / "csrc"
+ROCM = Path(os.environ.get("ROCM_PATH", "/opt/rocm"))
+
+HIPCC = shutil.which("hipcc") or str(ROCM / "bin" / "hipcc")
+CXX = shutil.which("g++") or "g++"
+
+# target name -> (compiler kind, sources relative to csrc/, extra flags)
+TARGETS = {
+    "vpsa_kernels": (
+        "hip",
+        ["kernels/elementwise.hip", "kernels/attention.hip", "kernels/kvcache.hip", "kernels/moe.hip"],
+        [],
+    ),
+    "vpsa_kvio": ("hip", ["kvio/kvio.cpp"], []),
+    "vpsa_comm": ("hip", ["comm/comm.cpp"], ["-lrccl"]),
+    "vpsa_routercore": ("cxx", ["routercore/routercore.cpp"], []),
+}
+
+# standalone executables: name -> (kind, sources, flags)
+BINARIES = {
+    "vpsa-picker": ("cxx", ["routercore/picker_service.cpp", "routercore/routercore.cpp"], ["-lpthread"]),
+    "vpsa-operator": ("cxx", ["operator/operator_main.cpp"], ["-lpthread"]),
+}
+
+
+def _stale(out: Path, srcs: list[Path]) -> bool:
+    if not out.exists():
+        return True
+    t = out.stat().st_mtime
+    deps = list(srcs)
+    for s in srcs:
+        deps.extend(s.parent.glob("*.h"))
+        deps.extend(s.parent.glob("*.hpp"))
+    return any(d.stat().st_mtime > t for d in deps if d.exists())
+
+
+def _run(cmd: list[str]) -> None:
+    print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
+def build_target(name: str, force: bool = False) -> Path | None:
+    if name in TARGETS:
+        kind, srcs, flags = TARGETS[name]
+        out = HERE / f"lib{name}.so"
+        shared = ["-shared", "-fPIC"]
+    else:
+        kind, srcs, flags = BINARIES[name]
+        out = HERE / name
+        shared = []
+    paths = [CSRC / s for s in srcs]
+    missing = [p for p in paths if not p.exists()]
+    if missing:
+        print(f"[build] skip {name}: missing {[str(m) for m in missing]}")
+        return None
+    if not force and not _stale(out, paths):
+        return out
+    if kind == "hip":
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", *shared,
+               "-fvisibility=hidden", "-I", str(CSRC), *map(str, paths), "-o", str(out), *flags]
+    else:
+        cmd = [CXX, "-O2", "-std=c++17", *shared, "-I", str(CSRC), *map(str, paths), "-o",
+               str(out), *flags]
+    _run(cmd)
+    return out
+
+
+def build_all(force: bool = False, targets: list[str] | None = None) -> dict[str, Path | None]:
+    names = targets or (list(TARGETS) + list(BINARIES))
+    return {n: build_target(n, force) for n in names}
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    res = build_all(force="--force" in sys.argv, targets=args or None)
+    for k, v in res.items():
+        print(f"{k}: {v}")

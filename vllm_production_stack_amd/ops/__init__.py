@@ -1,0 +1,318 @@
+"""Engine ops.  CUDA(HIP)-device tensors run the hand-written gfx950 kernels from
+``libvpsa_kernels.so`` (loaded with ctypes and launched on the current torch stream, so
+they are capturable into HIP graphs); CPU tensors run the PyTorch definitions in
+``reference.py``.  There is no silent GPU fallback: a GPU tensor with the library
+missing raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_float, c_int, c_long, c_void_p
+
+import torch
+
+from .. import _native
+from . import reference
+from .reference import PAGE, build_cos_sin  # noqa: F401
+
+HEAD_DIM_HIP = 128
+_lib = None
+
+
+def _kernels():
+    global _lib
+    if _lib is None:
+        lib = _native.load("vpsa_kernels")
+        for name in (
+            "vpsa_rmsnorm", "vpsa_rope_cache", "vpsa_silu_mul", "vpsa_argmax_bf16",
+            "vpsa_paged_prefill", "vpsa_paged_decode", "vpsa_kv_gather_pages",
+            "vpsa_kv_scatter_pages", "vpsa_cachegen_encode", "vpsa_cachegen_decode",
+            "vpsa_moe_topk_softmax", "vpsa_moe_align", "vpsa_moe_permute", "vpsa_moe_combine",
+        ):
+            getattr(lib, name).restype = c_int
+        _lib = lib
+    return _lib
+
+
+def native_loaded() -> bool:
+    return _lib is not None
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise RuntimeError(f"{name}: unsupported arguments (rc={rc})")
+
+
+def _bf16_cuda(*ts):
+    for t in ts:
+        if t is not None and (not t.is_cuda or t.dtype != torch.bfloat16):
+            raise TypeError("HIP kernels take bf16 device tensors")
+
+
+# --------------------------------------------------------------------------- norms
+def rms_norm(x, weight, eps, residual=None, out=None):
+    """y = rmsnorm(x [+ residual]) * weight.  ``residual`` is updated in place with the sum."""
+    if not x.is_cuda:
+        y = reference.rms_norm(x, weight, eps, residual)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+    _bf16_cuda(x, weight, residual)
+    hidden = x.shape[-1]
+    x2 = x.view(-1, hidden)
+    if x2.stride(-1) != 1:
+        raise ValueError("rms_norm: last dim must be contiguous")
+    if out is None:
+        out = torch.empty((x2.shape[0], hidden), dtype=x.dtype, device=x.device)
+    if residual is not None and not residual.is_contiguous():
+        raise ValueError("rms_norm: residual must be contiguous")
+    rc = _kernels().vpsa_rmsnorm(_p(x2), _p(residual), _p(weight), _p(out), c_int(x2.shape[0]),
+                                 c_int(hidden), c_long(x2.stride(0)), c_long(out.stride(0)),
+                                 c_float(eps), _stream())
+    _check(rc, "rms_norm")
+    return out.view(x.shape)
+
+
+# --------------------------------------------------------------------------- rope + cache write
+def rope_and_cache(qkv, positions, slots, cos_sin, pool, layer, n_q, n_kv, head_dim, rotary=True):
+    if not qkv.is_cuda:
+        return reference.rope_and_cache(qkv, positions, slots, cos_sin, pool, layer, n_q, n_kv,
+                                        head_dim, rotary)
+    _bf16_cuda(qkv, pool)
+    if head_dim != HEAD_DIM_HIP:
+        raise ValueError("HIP attention path is built for head_dim 128")
+    assert positions.dtype == torch.int32 and (slots is None or slots.dtype == torch.int64)
+    assert cos_sin.dtype == torch.float32 and cos_sin.shape[1] == head_dim
+    base = pool.data_ptr() + layer * pool.stride(1) * 2
+    rc = _kernels().vpsa_rope_cache(_p(qkv), _p(positions), _p(slots), _p(cos_sin), c_void_p(base),
+                                    c_int(qkv.shape[0]), c_long(qkv.stride(0)), c_int(n_q),
+                                    c_int(n_kv), c_long(pool.stride(0)), c_long(pool.stride(2)),
+                                    c_int(1 if rotary else 0), _stream())
+    _check(rc, "rope_and_cache")
+
+
+# --------------------------------------------------------------------------- attention
+def build_prefill_tiles(q_lens, n_q, n_kv):
+    """Host-side work list for the prefill kernel: one (sequence, first row) entry per query
+    tile, longest-context tiles first so the heaviest workgroups start earliest."""
+    g = n_q // n_kv
+    qt = 32 * (4 // min(g, 4))
+    seqs, q0s = [], []
+    for s, ql in enumerate(q_lens):
+        for q0 in range(0, ql, qt):
+            seqs.append(s)
+            q0s.append(q0)
+    order = sorted(range(len(seqs)), key=lambda i: -q0s[i])
+    return [seqs[i] for i in order], [q0s[i] for i in order]
+
+
+def paged_prefill(q, out, pool, layer, block_tables, cu_q, ctx_lens, tile_seq, tile_q0, n_q, n_kv,
+                  head_dim, scale):
+    if not q.is_cuda:
+        return reference.paged_prefill(q, out, pool, layer, block_tables, cu_q, ctx_lens, n_q,
+                                       n_kv, head_dim, scale)
+    _bf16_cuda(q, out, pool)
+    if head_dim != HEAD_DIM_HIP:
+        raise ValueError("HIP attention path is built for head_dim 128")
+    for t in (block_tables, cu_q, ctx_lens, tile_seq, tile_q0):
+        assert t.dtype == torch.int32 and t.is_cuda and t.is_contiguous()
+    assert tile_seq.numel() == tile_q0.numel()
+    assert cu_q.numel() == ctx_lens.numel() + 1 and block_tables.shape[0] >= ctx_lens.numel()
+    base = pool.data_ptr() + layer * pool.stride(1) * 2
+    rc = _kernels().vpsa_paged_prefill(
+        _p(q), c_long(q.stride(0)), _p(out), c_long(out.stride(0)), c_void_p(base),
+        c_long(pool.stride(0)), c_long(pool.stride(2)), _p(block_tables),
+        c_int(block_tables.stride(0)), _p(cu_q), _p(ctx_lens), _p(tile_seq), _p(tile_q0),
+        c_int(tile_seq.numel()), c_int(n_q), c_int(n_kv), c_float(scale), _stream())
+    _check(rc, "paged_prefill")
+
+
+def decode_num_splits(num_seqs: int, n_kv: int, max_ctx: int) -> int:
+    """Enough workgroups to cover 256 CUs a few times over, at least 256 keys per split."""
+    want = max(1, 1024 // max(1, num_seqs * n_kv))
+    by_len = max(1, max_ctx // 256)
+    return int(max(1, min(want, by_len, 64)))
+
+
+def paged_decode(q, out, pool, layer, block_tables, ctx_lens, n_q, n_kv, head_dim, scale,
+                 num_splits=1, ws_o=None, ws_ml=None):
+    if not q.is_cuda:
+        return reference.paged_decode(q, out, pool, layer, block_tables, ctx_lens, n_q, n_kv,
+                                      head_dim, scale)
+    _bf16_cuda(q, out, pool)
+    if head_dim != HEAD_DIM_HIP:
+        raise ValueError("HIP attention path is built for head_dim 128")
+    assert block_tables.dtype == torch.int32 and ctx_lens.dtype == torch.int32
+    n = q.shape[0]
+    assert block_tables.shape[0] >= n and ctx_lens.numel() >= n
+    if num_splits > 1:
+        if ws_o is None:
+            ws_o = torch.empty((n, n_q, num_splits, head_dim), dtype=torch.float32, device=q.device)
+            ws_ml = torch.empty((n, n_q, num_splits, 2), dtype=torch.float32, device=q.device)
+        assert ws_o.numel() >= n * n_q * num_splits * head_dim
+    base = pool.data_ptr() + layer * pool.stride(1) * 2
+    rc = _kernels().vpsa_paged_decode(
+        _p(q), c_long(q.stride(0)), _p(out), c_long(out.stride(0)), c_void_p(base),
+        c_long(pool.stride(0)), c_long(pool.stride(2)), _p(block_tables),
+        c_int(block_tables.stride(0)), _p(ctx_lens), _p(ws_o), _p(ws_ml), c_int(n), c_int(n_q),
+        c_int(n_kv), c_int(num_splits), c_float(scale), _stream())
+    _check(rc, "paged_decode")
+
+
+# --------------------------------------------------------------------------- MLP / sampling
+def silu_and_mul(x, out=None):
+    if not x.is_cuda:
+        y = reference.silu_and_mul(x)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+    _bf16_cuda(x)
+    inter = x.shape[-1] // 2
+    x2 = x.view(-1, 2 * inter)
+    assert x2.is_contiguous()
+    if out is None:
+        out = torch.empty((x2.shape[0], inter), dtype=x.dtype, device=x.device)
+    rc = _kernels().vpsa_silu_mul(_p(x2), _p(out), c_long(x2.shape[0]), c_int(inter), _stream())
+    _check(rc, "silu_and_mul")
+    return out.view(*x.shape[:-1], inter)
+
+
+def argmax(logits, out=None):
+    if not logits.is_cuda:
+        return reference.argmax(logits)
+    if logits.dtype != torch.bfloat16 or logits.stride(-1) != 1 or logits.stride(0) % 8 != 0:
+        return torch.argmax(logits, dim=-1)
+    if out is None:
+        out = torch.empty((logits.shape[0],), dtype=torch.int64, device=logits.device)
+    rc = _kernels().vpsa_argmax_bf16(_p(logits), _p(out), c_int(logits.shape[0]),
+                                     c_int(logits.shape[1]), c_long(logits.stride(0)), _stream())
+    _check(rc, "argmax")
+    return out
+
+
+# --------------------------------------------------------------------------- KV page movement
+def kv_gather_pages(pool, page_ids, staging):
+    """Copy whole pages (all layers) ``pool[page_ids]`` into contiguous ``staging``."""
+    if not pool.is_cuda:
+        staging.view(-1)[: page_ids.numel() * pool[0].numel()].view(page_ids.numel(), -1).copy_(
+            pool[page_ids.long()].reshape(page_ids.numel(), -1))
+        return
+    assert page_ids.dtype == torch.int64 and page_ids.is_cuda
+    page_bytes = pool.stride(0) * pool.element_size()
+    assert staging.numel() * staging.element_size() >= page_ids.numel() * page_bytes
+    rc = _kernels().vpsa_kv_gather_pages(_p(pool), _p(page_ids), _p(staging),
+                                         c_int(page_ids.numel()), c_long(page_bytes), _stream())
+    _check(rc, "kv_gather_pages")
+
+
+def kv_scatter_pages(staging, page_ids, pool):
+    if not pool.is_cuda:
+        pool[page_ids.long()] = staging.view(-1)[: page_ids.numel() * pool[0].numel()].view(
+            page_ids.numel(), *pool.shape[1:]).to(pool.dtype)
+        return
+    assert page_ids.dtype == torch.int64 and page_ids.is_cuda
+    page_bytes = pool.stride(0) * pool.element_size()
+    rc = _kernels().vpsa_kv_scatter_pages(_p(staging), _p(page_ids), _p(pool),
+                                          c_int(page_ids.numel()), c_long(page_bytes), _stream())
+    _check(rc, "kv_scatter_pages")
+
+
+def cachegen_encode(staging, levels, unit_elems, n_layers):
+    """bf16 staging -> (int8 symbols, fp32 group scales).  ``levels``: int32 tensor [n_layers]."""
+    if not staging.is_cuda:
+        return reference.cachegen_encode(staging, levels.tolist(), unit_elems, n_layers)
+    n = staging.numel()
+    sym = torch.empty((n,), dtype=torch.int8, device=staging.device)
+    scales = torch.empty((n // 64,), dtype=torch.float32, device=staging.device)
+    assert levels.dtype == torch.int32 and levels.is_cuda
+    rc = _kernels().vpsa_cachegen_encode(_p(staging), _p(sym), _p(scales), _p(levels), c_long(n),
+                                         c_long(unit_elems), c_int(n_layers), _stream())
+    _check(rc, "cachegen_encode")
+    return sym, scales
+
+
+def cachegen_decode(symbols, scales, unit_elems, out=None):
+    if not symbols.is_cuda:
+        y = reference.cachegen_decode(symbols, scales, unit_elems)
+        if out is not None:
+            out.view(-1).copy_(y)
+            return out
+        return y
+    n = symbols.numel()
+    if out is None:
+        out = torch.empty((n,), dtype=torch.bfloat16, device=symbols.device)
+    rc = _kernels().vpsa_cachegen_decode(_p(symbols), _p(scales), _p(out), c_long(n),
+                                         c_long(unit_elems), _stream())
+    _check(rc, "cachegen_decode")
+    return out
+
+
+# --------------------------------------------------------------------------- MoE routing
+def moe_topk_softmax(logits, topk, renorm=True):
+    if not logits.is_cuda:
+        return reference.moe_topk_softmax(logits, topk, renorm)
+    _bf16_cuda(logits)
+    t, e = logits.shape
+    w = torch.empty((t, topk), dtype=torch.float32, device=logits.device)
+    ids = torch.empty((t, topk), dtype=torch.int32, device=logits.device)
+    rc = _kernels().vpsa_moe_topk_softmax(_p(logits.contiguous()), _p(w), _p(ids), c_int(t),
+                                          c_int(e), c_int(topk), c_int(1 if renorm else 0),
+                                          _stream())
+    _check(rc, "moe_topk_softmax")
+    return w, ids
+
+
+def moe_align(ids, n_experts):
+    """ids [T, K] int32 -> (offsets [E+1], pos [T*K], sorted_tok [T*K])."""
+    t, k = ids.shape
+    if not ids.is_cuda:
+        flat = ids.reshape(-1).long()
+        order = torch.sort(flat, stable=True).indices
+        pos = torch.empty_like(order)
+        pos[order] = torch.arange(order.numel())
+        counts = torch.bincount(flat, minlength=n_experts)
+        offsets = torch.zeros(n_experts + 1, dtype=torch.int32)
+        offsets[1:] = counts.cumsum(0)
+        return offsets, pos.int(), (order // k).int()
+    offsets = torch.empty((n_experts + 1,), dtype=torch.int32, device=ids.device)
+    pos = torch.empty((t * k,), dtype=torch.int32, device=ids.device)
+    sorted_tok = torch.empty((t * k,), dtype=torch.int32, device=ids.device)
+    rc = _kernels().vpsa_moe_align(_p(ids.contiguous()), _p(offsets), _p(pos), _p(sorted_tok),
+                                   c_int(t * k), c_int(n_experts), c_int(k), _stream())
+    _check(rc, "moe_align")
+    return offsets, pos, sorted_tok
+
+
+def moe_permute(x, sorted_tok):
+    if not x.is_cuda:
+        return x[sorted_tok.long()]
+    _bf16_cuda(x)
+    xs = torch.empty((sorted_tok.numel(), x.shape[1]), dtype=x.dtype, device=x.device)
+    rc = _kernels().vpsa_moe_permute(_p(x.contiguous()), _p(sorted_tok), _p(xs),
+                                     c_int(sorted_tok.numel()), c_int(x.shape[1]), _stream())
+    _check(rc, "moe_permute")
+    return xs
+
+
+def moe_combine(y, weights, pos, tokens):
+    k = weights.shape[1]
+    if not y.is_cuda:
+        g = y[pos.long()].view(tokens, k, -1).float()
+        return (g * weights[:, :, None]).sum(1).to(y.dtype)
+    _bf16_cuda(y)
+    out = torch.empty((tokens, y.shape[1]), dtype=y.dtype, device=y.device)
+    rc = _kernels().vpsa_moe_combine(_p(y.contiguous()), _p(weights), _p(pos), _p(out),
+                                     c_int(tokens), c_int(y.shape[1]), c_int(k), _stream())
+    _check(rc, "moe_combine")
+    return out
