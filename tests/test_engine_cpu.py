@@ -1,0 +1,151 @@
+"""Engine core on CPU (PyTorch op definitions): the paged / chunked / prefix-cached /
+preempting execution must generate exactly what a dense full-recompute forward generates."""
+
+import copy
+
+import pytest
+import torch
+
+from vllm_production_stack_amd.engine.config import EngineConfig
+from vllm_production_stack_amd.engine.llm_engine import LLMEngine
+from vllm_production_stack_amd.engine.request import SamplingParams
+from vllm_production_stack_amd.ops import reference as ref
+
+
+def dense_next_token(model, ids):
+    """Full-recompute greedy next token with the engine's weights (no cache, no paging)."""
+    cfg = model.cfg
+    x = model.embed[torch.tensor(ids)].float()
+    t = len(ids)
+    half = cfg.head_dim // 2
+    cs = model.cos_sin[:t]
+    cos, sin = cs[:, None, :half], cs[:, None, half:]
+    mask = torch.triu(torch.ones(t, t, dtype=torch.bool), 1)
+    for lw in model.layers:
+        h = ref.rms_norm(x, lw.ln1.float(), cfg.norm_eps)
+        qkv = (h @ lw.wqkv.float().t()).view(t, -1, cfg.head_dim)
+        q, k, v = qkv[:, :cfg.num_heads], qkv[:, cfg.num_heads:cfg.num_heads + cfg.num_kv_heads], \
+            qkv[:, cfg.num_heads + cfg.num_kv_heads:]
+
+        def rot(z):
+            a, b = z[..., :half], z[..., half:]
+            return torch.cat([a * cos - b * sin, b * cos + a * sin], -1)
+
+        q, k = rot(q), rot(k)
+        g = cfg.num_heads // cfg.num_kv_heads
+        k = k.repeat_interleave(g, 1)
+        v = v.repeat_interleave(g, 1)
+        sc = torch.einsum("qhd,khd->hqk", q, k) / cfg.head_dim ** 0.5
+        sc = sc.masked_fill(mask, float("-inf"))
+        o = torch.einsum("hqk,khd->qhd", sc.softmax(-1), v).reshape(t, -1)
+        x = x + o @ lw.wo.float().t()
+        h = ref.rms_norm(x, lw.ln2.float(), cfg.norm_eps)
+        if cfg.num_experts:
+            p = (h @ lw.router.float().t()).softmax(-1)
+            w, idx = p.topk(cfg.num_experts_per_tok, -1)
+            w = w / w.sum(-1, keepdim=True)
+            y = torch.zeros_like(x)
+            for e in range(cfg.num_experts):
+                gu = h @ lw.w13[e].float().t()
+                a = ref.silu_and_mul(gu) @ lw.w2[e].float().t()
+                y += a * (w * (idx == e)).sum(-1, keepdim=True)
+            x = x + y
+        else:
+            gu = h @ lw.w_gate_up.float().t()
+            x = x + ref.silu_and_mul(gu) @ lw.w_down.float().t()
+    h = ref.rms_norm(x[-1:], model.norm.float(), cfg.norm_eps)
+    return int((h @ model.lm_head.float().t()).argmax(-1))
+
+
+def make_engine(model="tiny-llama", **kw):
+    cfg = EngineConfig(model=model, device="cpu", dtype="float32", max_model_len=1024,
+                       max_num_seqs=8, max_num_batched_tokens=kw.pop("budget", 256),
+                       num_gpu_blocks_override=kw.pop("pages", 64), **kw)
+    return LLMEngine(cfg)
+
+
+@pytest.mark.parametrize("model", ["tiny-llama", "tiny-llama-gqa", "tiny-mixtral"])
+def test_greedy_matches_dense(model):
+    eng = make_engine(model)
+    g = torch.Generator().manual_seed(0)
+    prompt = torch.randint(16, 500, (150,), generator=g).tolist()
+    out = eng.generate([prompt], SamplingParams(max_tokens=6, temperature=0, ignore_eos=True))[0]
+    ids = list(prompt)
+    for tok in out:
+        assert dense_next_token(eng.runner.model, ids) == tok
+        ids.append(tok)
+
+
+def test_chunked_prefill_equals_whole_prompt():
+    g = torch.Generator().manual_seed(1)
+    prompt = torch.randint(16, 500, (300,), generator=g).tolist()
+    sp = SamplingParams(max_tokens=5, temperature=0, ignore_eos=True)
+    a = make_engine(budget=64).generate([prompt], copy.deepcopy(sp))[0]
+    b = make_engine(budget=1024).generate([prompt], copy.deepcopy(sp))[0]
+    c = make_engine(budget=64, enable_chunked_prefill=False).generate([prompt], copy.deepcopy(sp))[0]
+    assert a == b == c
+
+
+def test_prefix_cache_hit_same_tokens_and_counted():
+    eng = make_engine()
+    g = torch.Generator().manual_seed(2)
+    base = torch.randint(16, 500, (200,), generator=g).tolist()
+    sp = SamplingParams(max_tokens=4, temperature=0, ignore_eos=True)
+    first = eng.generate([base], copy.deepcopy(sp))[0]
+    assert eng.bm.hits == 0
+    # second turn: previous prompt + answer + new question
+    turn2 = base + first + [20, 21, 22]
+    r = eng.add_request(turn2, copy.deepcopy(sp))
+    while eng.has_work():
+        eng.step()
+    assert r.num_cached_tokens == 192  # three full 64-token pages of shared history
+    assert eng.bm.hits == 192
+    fresh = make_engine().generate([turn2], copy.deepcopy(sp))[0]
+    assert r.output_ids == fresh
+
+
+def test_batched_requests_are_independent():
+    eng = make_engine()
+    g = torch.Generator().manual_seed(3)
+    prompts = [torch.randint(16, 500, (n,), generator=g).tolist() for n in (5, 70, 131, 64)]
+    sp = SamplingParams(max_tokens=8, temperature=0, ignore_eos=True)
+    together = eng.generate(prompts, copy.deepcopy(sp))
+    for p, t in zip(prompts, together):
+        alone = make_engine().generate([p], copy.deepcopy(sp))[0]
+        assert alone == t
+
+
+def test_preemption_recomputes_correctly():
+    g = torch.Generator().manual_seed(4)
+    prompts = [torch.randint(16, 500, (100,), generator=g).tolist() for _ in range(4)]
+    sp = SamplingParams(max_tokens=40, temperature=0, ignore_eos=True)
+    small = make_engine(pages=7, enable_prefix_caching=False)
+    got = small.generate(prompts, copy.deepcopy(sp))
+    assert small.scheduler.num_preemptions > 0
+    big = make_engine(pages=64).generate(prompts, copy.deepcopy(sp))
+    assert got == big
+
+
+def test_opt_model_runs_on_cpu():
+    eng = make_engine("tiny-opt")
+    out = eng.generate([[5, 6, 7, 8, 9]], SamplingParams(max_tokens=5, temperature=0, ignore_eos=True))
+    assert len(out[0]) == 5
+
+
+def test_stop_conditions_and_sampling_seed():
+    eng = make_engine()
+    sp = SamplingParams(max_tokens=10, temperature=0.8, top_p=0.9, top_k=50, seed=7, ignore_eos=True)
+    a = eng.generate([[17, 18, 19]], copy.deepcopy(sp))[0]
+    b = eng.generate([[17, 18, 19]], copy.deepcopy(sp))[0]
+    assert a == b and len(a) == 10
+    stop_tok = a[2]
+    sp2 = copy.deepcopy(sp)
+    sp2.stop_token_ids = [stop_tok]
+    c = eng.generate([[17, 18, 19]], sp2)[0]
+    assert c == a[: a.index(stop_tok) + 1]
+
+
+def test_context_limit_is_enforced():
+    eng = make_engine()
+    with pytest.raises(ValueError):
+        eng.add_request(list(range(16, 16 + 1024)), SamplingParams())

@@ -1,0 +1,177 @@
+"""The engine core: request intake, the step loop body, stop handling, statistics.
+
+``LLMEngine.step()`` = schedule -> execute on the GPU -> commit tokens / publish pages /
+finish sequences.  ``AsyncLLMEngine`` (async_engine.py) drives it from a dedicated thread
+and fans results out to asyncio consumers; tests and the benchmark can also call ``step``
+directly.
+"""
+
+from __future__ import annotations
+
+import logging
+import time
+import uuid
+
+import torch
+
+from .block_manager import PAGE, BlockManager
+from .config import EngineConfig, resolve_model
+from .metrics import EngineMetrics
+from .model_runner import ModelRunner
+from .request import Request, RequestState, SamplingParams, StepOutput
+from .scheduler import Scheduler
+from .tokenizer import load_tokenizer
+
+log = logging.getLogger("vpsa.engine")
+
+
+class LLMEngine:
+    def __init__(self, cfg: EngineConfig, device: torch.device | None = None):
+        self.cfg = cfg
+        self.model_cfg, self.ckpt_dir = resolve_model(cfg.model)
+        self.device = device or cfg.resolve_device()
+        self.runner = ModelRunner(cfg, self.model_cfg, self.ckpt_dir, self.device)
+        self.max_model_len = self.runner.max_model_len
+        self.tokenizer = load_tokenizer(self.ckpt_dir, self.model_cfg.vocab_size, cfg.chat_template)
+        self.connector = None
+        self.bm = BlockManager(self.runner.num_pages, cfg.enable_prefix_caching or cfg.kv_offload.enabled)
+        self.scheduler = Scheduler(self.bm, cfg.max_num_seqs, cfg.max_num_batched_tokens,
+                                   self.max_model_len, cfg.enable_chunked_prefill)
+        self.metrics = EngineMetrics(cfg.model_name)
+        self.requests: dict[str, Request] = {}
+        self.eos_ids = {self.tokenizer.eos_token_id, self.model_cfg.eos_token_id} if self.ckpt_dir else {
+            self.tokenizer.eos_token_id}
+        self.lora_manager = None
+        self.step_count = 0
+        self._init_kv_tiers()
+        log.info("engine ready: %d KV pages (%d tokens, %.1f GiB), max_model_len=%d",
+                 self.runner.num_pages, self.runner.num_pages * PAGE,
+                 self.runner.num_pages * self.runner.page_bytes / 2**30, self.max_model_len)
+
+    def _init_kv_tiers(self) -> None:
+        off = self.cfg.kv_offload
+        kvt = self.cfg.kv_transfer
+        if not (off.enabled or off.enable_pd or off.enable_controller or (kvt and kvt.kv_connector)):
+            return
+        from ..kv.connector import KVConnector
+
+        self.connector = KVConnector(self, off, kvt)
+        self.scheduler.connector = self.connector
+        self.bm.on_evict = self.connector.on_evict
+
+    # ------------------------------------------------------------------ intake
+    def add_request(self, prompt_ids: list[int], params: SamplingParams,
+                    request_id: str | None = None, lora_name: str | None = None,
+                    kv_transfer_params: dict | None = None) -> Request:
+        rid = request_id or uuid.uuid4().hex
+        if len(prompt_ids) == 0:
+            prompt_ids = [self.tokenizer.bos_token_id or 0]
+        if len(prompt_ids) >= self.max_model_len:
+            raise ValueError(
+                f"prompt has {len(prompt_ids)} tokens; the context limit is {self.max_model_len}")
+        params.max_tokens = max(1, min(params.max_tokens, self.max_model_len - len(prompt_ids)))
+        req = Request(rid, list(prompt_ids), params, lora_name=lora_name,
+                      kv_transfer_params=kv_transfer_params)
+        if lora_name and self.lora_manager is not None:
+            req.lora_slot = self.lora_manager.slot_of(lora_name)
+        self.requests[rid] = req
+        self.scheduler.add(req)
+        return req
+
+    def abort(self, request_id: str) -> None:
+        req = self.scheduler.abort(request_id)
+        self.requests.pop(request_id, None)
+        if req is not None:
+            self.runner.sampler.forget(request_id)
+
+    def has_work(self) -> bool:
+        return self.scheduler.has_work()
+
+    # ------------------------------------------------------------------ step
+    def step(self) -> list[StepOutput]:
+        out = self.scheduler.schedule()
+        self.step_count += 1
+        if out.empty:
+            self.metrics.update_scheduler(self.scheduler, self.bm)
+            return []
+        now = time.time()
+        results = self.runner.execute(out)
+        sampled = {id(s): (tok, info) for s, tok, info in results}
+        outputs: list[StepOutput] = []
+        fresh_pages: list[tuple[int, int]] = []
+        for s in out.decodes + out.prefills:
+            req = s.req
+            if s.start < req.prompt_len:
+                self.metrics.prompt_tokens.inc(min(s.n, req.prompt_len - s.start))
+            fresh_pages.extend(self.scheduler.commit(s))
+            if id(s) not in sampled:
+                continue
+            tok, _info = sampled[id(s)]
+            req.output_ids.append(tok)
+            self.metrics.generation_tokens.inc()
+            t = time.time()
+            if req.first_token is None:
+                req.first_token = t
+                self.metrics.ttft.observe(t - req.arrival)
+                if req.first_scheduled:
+                    self.metrics.queue_time.observe(req.first_scheduled - req.arrival)
+            elif req.last_token is not None:
+                self.metrics.tpot.observe(t - req.last_token)
+            req.last_token = t
+            reason = self._stop_reason(req, tok)
+            if reason:
+                self.scheduler.finish(req, reason)
+                self.requests.pop(req.request_id, None)
+                self.runner.sampler.forget(req.request_id)
+                self.metrics.e2e.observe(t - req.arrival)
+                self.metrics.success.inc()
+                if self.connector is not None:
+                    self.connector.on_request_finished(req)
+            outputs.append(StepOutput(req.request_id, [tok], reason is not None, reason,
+                                      req.prompt_len, len(req.output_ids), req.num_cached_tokens + req.num_external_tokens))
+        if self.connector is not None and fresh_pages:
+            self.connector.store_pages(fresh_pages)
+        self.metrics.update_scheduler(self.scheduler, self.bm)
+        del now
+        return outputs
+
+    def _stop_reason(self, req: Request, tok: int) -> str | None:
+        p = req.params
+        n_out = len(req.output_ids)
+        if n_out >= p.min_tokens:
+            if not p.ignore_eos and tok in self.eos_ids:
+                return "stop"
+            if tok in p.stop_token_ids:
+                return "stop"
+        if n_out >= p.max_tokens:
+            return "length"
+        if req.num_tokens >= self.max_model_len:
+            return "length"
+        return None
+
+    # ------------------------------------------------------------------ convenience
+    def generate(self, prompts: list[list[int]], params: SamplingParams) -> list[list[int]]:
+        """Blocking helper: run the prompts to completion, return generated ids per prompt."""
+        import copy
+
+        reqs = [self.add_request(p, copy.deepcopy(params)) for p in prompts]
+        while self.has_work():
+            self.step()
+        return [r.output_ids for r in reqs]
+
+    # ------------------------------------------------------------------ sleep mode
+    def sleep(self, level: int = 1) -> int:
+        assert not self.scheduler.running, "cannot sleep with requests in flight"
+        self.bm.reset_prefix_cache()
+        return self.runner.sleep(level)
+
+    def wake_up(self) -> None:
+        self.runner.wake_up()
+
+    @property
+    def is_sleeping(self) -> bool:
+        return self.runner.sleeping
+
+    def shutdown(self) -> None:
+        if self.connector is not None:
+            self.connector.close()

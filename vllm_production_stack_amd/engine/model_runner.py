@@ -1,0 +1,311 @@
+"""Executes scheduler output on one GPU: batch assembly, model forward, sampling.
+
+Memory plan (per process = per GPU): weights, then one contiguous paged KV pool sized from
+what is left of ``gpu_memory_utilization`` x HBM after an activation reserve.  The pool is
+laid out [page][layer][K|V][kv_head][64*128] so a page's whole depth (all layers) is one
+contiguous run: offload / peer transfer of a page is a single large copy.
+
+Decode-only steps replay a HIP graph captured per padded batch size (the launch-bound
+inner loop: ~10 launches per layer); mixed and prefill steps run eagerly.
+"""
+
+from __future__ import annotations
+
+import logging
+import time
+
+import torch
+
+from .. import ops
+from ..models.batch import BatchMeta
+from ..models.loader import build_model
+from ..parallel.state import get_tp
+from .block_manager import PAGE
+from .config import EngineConfig, ModelConfig
+from .sampler import Sampler
+from .scheduler import ScheduledSeq, SchedulerOutput
+
+log = logging.getLogger("vpsa.runner")
+
+_GRAPH_BUCKETS = [1, 2, 4, 8, 12, 16, 24, 32, 40, 48, 64, 80, 96, 128, 160, 192, 256]
+
+
+class ModelRunner:
+    def __init__(self, cfg: EngineConfig, model_cfg: ModelConfig, ckpt_dir, device: torch.device):
+        self.cfg = cfg
+        self.model_cfg = model_cfg
+        self.device = device
+        self.dtype = cfg.torch_dtype() if device.type == "cuda" else (
+            torch.float32 if cfg.dtype in ("auto", "float32", "float") else cfg.torch_dtype())
+        self.max_model_len = cfg.max_model_len or min(model_cfg.max_position_embeddings, 32768)
+        if device.type == "cuda":
+            torch.cuda.set_device(device)
+        t0 = time.time()
+        self.model = build_model(model_cfg, self.dtype, device, self.max_model_len, ckpt_dir,
+                                 cfg.seed, cfg.load_format)
+        log.info("model %s ready: %.2f GiB weights in %.1fs", model_cfg.name,
+                 self.model.weight_bytes() / 2**30, time.time() - t0)
+        self.n_kv_local = self.model.n_kv
+        self.page_elems = model_cfg.num_layers * 2 * self.n_kv_local * PAGE * model_cfg.head_dim
+        self.page_bytes = self.page_elems * torch.empty((), dtype=self.dtype).element_size()
+        self.max_pages_per_seq = (self.max_model_len + PAGE - 1) // PAGE
+        self.num_pages = self._plan_pages()
+        self.pool = torch.zeros(
+            (self.num_pages, model_cfg.num_layers, 2, self.n_kv_local, PAGE * model_cfg.head_dim),
+            dtype=self.dtype, device=device)
+        self.sampler = Sampler(device, cfg.seed)
+        self.use_graphs = device.type == "cuda" and not cfg.enforce_eager
+        self._graphs: dict[int, dict] = {}
+        self._graph_pool = None
+        self._pin = device.type == "cuda"
+        self.sleeping = False
+        self._sleep_stash: list[tuple[torch.Tensor, torch.Tensor]] = []
+
+    # ------------------------------------------------------------------ memory plan
+    def _plan_pages(self) -> int:
+        if self.cfg.num_gpu_blocks_override:
+            return int(self.cfg.num_gpu_blocks_override)
+        mc = self.model_cfg
+        if self.device.type != "cuda":
+            # CPU replicas: a modest pool (enough for max_num_seqs short sequences)
+            want = max(64, min(4096, self.cfg.max_num_seqs * 8))
+            return want
+        torch.cuda.synchronize()
+        free, total = torch.cuda.mem_get_info(self.device)
+        budget = total * self.cfg.gpu_memory_utilization - (total - free)
+        rows = self.cfg.max_num_batched_tokens if self.cfg.enable_chunked_prefill else max(
+            self.cfg.max_num_batched_tokens, self.max_model_len)
+        inter = mc.intermediate_size // get_tp().size
+        per_row = (mc.q_size + 2 * mc.kv_size + mc.q_size + 3 * inter + 4 * mc.hidden_size) * 2
+        if mc.num_experts:
+            per_row += 3 * inter * 2 * mc.num_experts_per_tok
+        reserve = int(rows * per_row * 1.25) + self.cfg.max_num_seqs * mc.vocab_size * 6 + (2 << 30)
+        pages = int((budget - reserve) // self.page_bytes)
+        if pages < self.max_pages_per_seq:
+            raise MemoryError(
+                f"not enough HBM for one sequence of max_model_len={self.max_model_len}: "
+                f"{pages} pages of {self.page_bytes >> 20} MiB available")
+        return pages
+
+    # ------------------------------------------------------------------ batch assembly
+    def _to_dev(self, data: list[int], dtype: torch.dtype) -> torch.Tensor:
+        t = torch.tensor(data, dtype=dtype)
+        if self._pin:
+            return t.pin_memory().to(self.device, non_blocking=True)
+        return t
+
+    def _build(self, decodes: list[ScheduledSeq], prefills: list[ScheduledSeq]):
+        ids: list[int] = []
+        pos: list[int] = []
+        slots: list[int] = []
+        logits_rows: list[int] = []
+        sample_seqs: list[ScheduledSeq] = []
+        row = 0
+        for s in decodes:
+            r = s.req
+            tok_idx = s.start
+            ids.append(r.prompt_ids[tok_idx] if tok_idx < r.prompt_len else r.output_ids[tok_idx - r.prompt_len])
+            pos.append(tok_idx)
+            slots.append(r.pages[tok_idx // PAGE] * PAGE + tok_idx % PAGE)
+            if s.samples:
+                logits_rows.append(row)
+                sample_seqs.append(s)
+            row += 1
+        for s in prefills:
+            r = s.req
+            if s.start + s.n <= r.prompt_len:
+                ids.extend(r.prompt_ids[s.start:s.start + s.n])
+            else:
+                ids.extend(r.all_ids[s.start:s.start + s.n])
+            pos.extend(range(s.start, s.start + s.n))
+            pages = r.pages
+            slots.extend(pages[t // PAGE] * PAGE + t % PAGE for t in range(s.start, s.start + s.n))
+            row += s.n
+            if s.samples:
+                logits_rows.append(row - 1)
+                sample_seqs.append(s)
+        meta = BatchMeta(positions=self._to_dev(pos, torch.int32),
+                         slots=self._to_dev(slots, torch.int64), num_decode=len(decodes),
+                         num_prefill_seqs=len(prefills))
+        if decodes:
+            width = max(len(s.req.pages) for s in decodes)
+            bt = [s.req.pages + [0] * (width - len(s.req.pages)) for s in decodes]
+            meta.dec_block_tables = self._to_dev(bt, torch.int32)
+            ctx = [s.start + 1 for s in decodes]
+            meta.dec_ctx_lens = self._to_dev(ctx, torch.int32)
+            meta.dec_num_splits = ops.decode_num_splits(len(decodes), self.n_kv_local, max(ctx))
+        if prefills:
+            width = max(len(s.req.pages) for s in prefills)
+            bt = [s.req.pages + [0] * (width - len(s.req.pages)) for s in prefills]
+            meta.pre_block_tables = self._to_dev(bt, torch.int32)
+            q_lens = [s.n for s in prefills]
+            cu = [0]
+            for q in q_lens:
+                cu.append(cu[-1] + q)
+            meta.pre_cu_q = self._to_dev(cu, torch.int32)
+            meta.pre_ctx_lens = self._to_dev([s.start + s.n for s in prefills], torch.int32)
+            if self.device.type == "cuda":
+                ts, tq = ops.build_prefill_tiles(q_lens, self.model.n_q, self.model.n_kv)
+                meta.pre_tile_seq = self._to_dev(ts, torch.int32)
+                meta.pre_tile_q0 = self._to_dev(tq, torch.int32)
+        meta.logits_rows = self._to_dev(logits_rows, torch.int64) if logits_rows else None
+        if self.model.lora is not None:
+            lslots = [s.req.lora_slot for s in decodes]
+            for s in prefills:
+                lslots.extend([s.req.lora_slot] * s.n)
+            if any(x >= 0 for x in lslots):
+                meta.lora_slots = self._to_dev(lslots, torch.int64)
+        return self._to_dev(ids, torch.int64), meta, sample_seqs
+
+    # ------------------------------------------------------------------ execution
+    @torch.inference_mode()
+    def execute(self, out: SchedulerOutput) -> list[tuple[ScheduledSeq, int, dict | None]]:
+        """Run one step; returns (sequence, sampled token, logprob info) per sampling sequence."""
+        if out.empty:
+            return []
+        for s in out.decodes + out.prefills:
+            ev = s.req.load_event
+            if ev is not None:
+                if self.device.type == "cuda" and hasattr(ev, "record"):
+                    torch.cuda.current_stream().wait_event(ev)
+                elif hasattr(ev, "wait"):
+                    ev.wait()
+                s.req.load_event = None
+        if (self.use_graphs and not out.prefills and self.model.lora is None
+                and all(s.samples for s in out.decodes)
+                and len(out.decodes) <= _GRAPH_BUCKETS[-1]):
+            return self._execute_decode_graph(out.decodes)
+        ids, meta, sample_seqs = self._build(out.decodes, out.prefills)
+        hidden = self.model.forward(ids, self.pool, meta)
+        if not sample_seqs:
+            return []
+        logits = self.model.compute_logits(hidden)
+        toks, infos = self.sampler.sample(logits, [s.req for s in sample_seqs])
+        return list(zip(sample_seqs, toks, infos))
+
+    # ------------------------------------------------------------------ HIP-graph decode
+    def _bucket(self, n: int) -> int:
+        for b in _GRAPH_BUCKETS:
+            if b >= n:
+                return b
+        return n
+
+    def _capture(self, bsz: int) -> dict:
+        dev = self.device
+        mp = self.max_pages_per_seq
+        st = {
+            "ids": torch.zeros(bsz, dtype=torch.int64, device=dev),
+            "pos": torch.zeros(bsz, dtype=torch.int32, device=dev),
+            "slots": torch.full((bsz,), -1, dtype=torch.int64, device=dev),
+            "bt": torch.zeros((bsz, mp), dtype=torch.int32, device=dev),
+            "ctx": torch.zeros(bsz, dtype=torch.int32, device=dev),
+        }
+        splits = max(1, min(32, 1024 // max(1, bsz * self.n_kv_local)))
+        mc = self.model_cfg
+        ws_o = torch.empty((bsz, self.model.n_q, splits, mc.head_dim), dtype=torch.float32, device=dev)
+        ws_ml = torch.empty((bsz, self.model.n_q, splits, 2), dtype=torch.float32, device=dev)
+        meta = BatchMeta(positions=st["pos"], slots=st["slots"], num_decode=bsz,
+                         dec_block_tables=st["bt"], dec_ctx_lens=st["ctx"], dec_num_splits=splits,
+                         dec_ws_o=ws_o, dec_ws_ml=ws_ml, logits_rows=None)
+
+        def run():
+            hidden = self.model.forward(st["ids"], self.pool, meta)
+            logits = self.model.compute_logits(hidden)
+            return logits, ops.argmax(logits)
+
+        # warm up on a side stream (library workspaces, lazy inits), then capture
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            run()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self._graph_pool):
+            logits, toks = run()
+        if self._graph_pool is None:
+            self._graph_pool = g.pool()
+        st.update(graph=g, logits=logits, toks=toks)
+        return st
+
+    def _execute_decode_graph(self, decodes: list[ScheduledSeq]):
+        n = len(decodes)
+        bsz = self._bucket(n)
+        st = self._graphs.get(bsz)
+        if st is None:
+            t0 = time.time()
+            st = self._capture(bsz)
+            self._graphs[bsz] = st
+            log.info("captured decode graph for batch %d in %.2fs", bsz, time.time() - t0)
+        mp = self.max_pages_per_seq
+        ids, pos, slots, ctx = [0] * bsz, [0] * bsz, [-1] * bsz, [0] * bsz
+        bt = torch.zeros((bsz, mp), dtype=torch.int32)
+        for i, s in enumerate(decodes):
+            r = s.req
+            t = s.start
+            ids[i] = r.output_ids[t - r.prompt_len] if t >= r.prompt_len else r.prompt_ids[t]
+            pos[i] = t
+            slots[i] = r.pages[t // PAGE] * PAGE + t % PAGE
+            ctx[i] = t + 1
+            bt[i, : len(r.pages)] = torch.tensor(r.pages, dtype=torch.int32)
+        st["ids"].copy_(self._to_dev(ids, torch.int64), non_blocking=True)
+        st["pos"].copy_(self._to_dev(pos, torch.int32), non_blocking=True)
+        st["slots"].copy_(self._to_dev(slots, torch.int64), non_blocking=True)
+        st["ctx"].copy_(self._to_dev(ctx, torch.int32), non_blocking=True)
+        st["bt"].copy_(bt.pin_memory().to(self.device, non_blocking=True), non_blocking=True)
+        st["graph"].replay()
+        reqs = [s.req for s in decodes]
+        toks, infos = self.sampler.sample(st["logits"], reqs, st["toks"])
+        return list(zip(decodes, toks, infos))
+
+    def warmup(self, batch_sizes: list[int] | None = None) -> None:
+        if not self.use_graphs:
+            return
+        for b in batch_sizes or [1]:
+            if b not in self._graphs and b <= self.cfg.max_num_seqs:
+                self._graphs[self._bucket(b)] = self._capture(self._bucket(b))
+
+    # ------------------------------------------------------------------ sleep / wake
+    def sleep(self, level: int = 1) -> int:
+        """Release HBM: weights to pinned host memory (level 1) or dropped (level 2); the KV
+        pool is freed.  Returns bytes released."""
+        if self.sleeping:
+            return 0
+        freed = 0
+        self._graphs.clear()
+        self._graph_pool = None
+        if self.device.type == "cuda":
+            for t in self.model.weight_tensors():
+                host = None
+                if level == 1:
+                    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                    host.copy_(t, non_blocking=True)
+                self._sleep_stash.append((t, host))
+                freed += t.numel() * t.element_size()
+            torch.cuda.synchronize()
+            for t, _ in self._sleep_stash:
+                t.set_(torch.empty(0, dtype=t.dtype, device=self.device).untyped_storage(), 0, (0,))
+        freed += self.pool.numel() * self.pool.element_size()
+        self._pool_shape = tuple(self.pool.shape)
+        self.pool = torch.empty(0, dtype=self.dtype, device=self.device)
+        if self.device.type == "cuda":
+            torch.cuda.empty_cache()
+        self.sleeping = True
+        return freed
+
+    def wake_up(self) -> None:
+        if not self.sleeping:
+            return
+        if self.device.type == "cuda":
+            for t, host in self._sleep_stash:
+                shape = host.shape if host is not None else None
+                if host is not None:
+                    fresh = host.to(self.device, non_blocking=True)
+                    t.set_(fresh.untyped_storage(), 0, shape, fresh.stride())
+            torch.cuda.synchronize()
+            if any(h is None for _, h in self._sleep_stash):
+                self.model.layers.clear()
+                self.model.init_random(self.cfg.seed)
+        self._sleep_stash = []
+        self.pool = torch.zeros(self._pool_shape, dtype=self.dtype, device=self.device)
+        self.sleeping = False

@@ -1,0 +1,201 @@
+"""Tokenizers: a HF ``tokenizers`` wrapper when the checkpoint directory ships one, and a
+deterministic synthetic word-level tokenizer for random-init serving (no files, no network).
+
+The synthetic tokenizer maps one whitespace-delimited word to one id, so the benchmark's
+"N repeated words" prompts are exactly N tokens, and ``decode`` followed by ``encode``
+reproduces the same ids - generated answers re-sent as chat history therefore hit the
+prefix cache, exactly like a real tokenizer's round trip.
+"""
+
+from __future__ import annotations
+
+import json
+import re
+from pathlib import Path
+
+import xxhash
+
+_SPECIALS = ["<|begin_of_text|>", "<|end_of_text|>", "<|start_header_id|>", "<|end_header_id|>",
+             "<|eot_id|>", "<|pad|>", "<|python_tag|>", "<|eom_id|>"]
+
+
+class BaseTokenizer:
+    eos_token_id: int = 2
+    bos_token_id: int | None = 1
+    vocab_size: int = 0
+    chat_template: str | None = None
+
+    def encode(self, text: str, add_special_tokens: bool = True) -> list[int]:
+        raise NotImplementedError
+
+    def decode(self, ids: list[int], skip_special_tokens: bool = True) -> str:
+        raise NotImplementedError
+
+    # -- chat -------------------------------------------------------------------
+    @staticmethod
+    def _content_text(content) -> str:
+        if isinstance(content, str):
+            return content
+        if isinstance(content, list):
+            return "\n".join(p.get("text", "") for p in content
+                             if isinstance(p, dict) and p.get("type", "text") == "text")
+        return "" if content is None else str(content)
+
+    def render_chat(self, messages: list[dict], add_generation_prompt: bool = True,
+                    tools: list | None = None) -> str:
+        if self.chat_template:
+            try:
+                import jinja2
+
+                env = jinja2.Environment()
+                env.globals["raise_exception"] = lambda m: (_ for _ in ()).throw(ValueError(m))
+                return env.from_string(self.chat_template).render(
+                    messages=messages, add_generation_prompt=add_generation_prompt, tools=tools,
+                    bos_token="<|begin_of_text|>", eos_token="<|eot_id|>")
+            except ImportError:
+                pass
+        out = ["<|begin_of_text|>"]
+        if tools:
+            out.append("<|start_header_id|> system <|end_header_id|> "
+                       "You may call tools by answering with a JSON object "
+                       '{"name": ..., "parameters": ...}. Tools: ' + json.dumps(tools) + " <|eot_id|>")
+        for m in messages:
+            text = self._content_text(m.get("content"))
+            if m.get("tool_calls"):
+                text += " " + json.dumps(m["tool_calls"])
+            out.append(f"<|start_header_id|> {m.get('role', 'user')} <|end_header_id|> {text} <|eot_id|>")
+        if add_generation_prompt:
+            out.append("<|start_header_id|> assistant <|end_header_id|>")
+        return " ".join(out)
+
+    def encode_chat(self, messages: list[dict], add_generation_prompt: bool = True,
+                    tools: list | None = None) -> list[int]:
+        return self.encode(self.render_chat(messages, add_generation_prompt, tools),
+                           add_special_tokens=False)
+
+
+class SyntheticTokenizer(BaseTokenizer):
+    """Word-level hashing tokenizer.  ids [0, 16) are special tokens."""
+
+    _WORD = re.compile(r"<\|[a-z_]+\|>|\S+")
+
+    def __init__(self, vocab_size: int, eos_token_id: int | None = None):
+        self.vocab_size = vocab_size
+        self._special = {s: i for i, s in enumerate(_SPECIALS)}
+        self._special_rev = {i: s for s, i in self._special.items()}
+        self.bos_token_id = self._special["<|begin_of_text|>"]
+        self.eos_token_id = self._special["<|eot_id|>"]
+        self._base = 16
+        self._space = max(1, vocab_size - self._base)
+        self._words: dict[int, str] = {}
+
+    def _word_id(self, w: str) -> int:
+        if w in self._special:
+            return self._special[w]
+        if w[0] == "t" and w[1:].isdigit():
+            v = int(w[1:])
+            if self._base <= v < self.vocab_size:
+                return v
+        i = self._base + xxhash.xxh32_intdigest(w.encode()) % self._space
+        self._words.setdefault(i, w)
+        return i
+
+    def encode(self, text: str, add_special_tokens: bool = True) -> list[int]:
+        ids = [self._word_id(w) for w in self._WORD.findall(text)]
+        if add_special_tokens and (not ids or ids[0] != self.bos_token_id):
+            ids.insert(0, self.bos_token_id)
+        return ids
+
+    def decode(self, ids: list[int], skip_special_tokens: bool = True) -> str:
+        words = []
+        for i in ids:
+            if i in self._special_rev:
+                if not skip_special_tokens:
+                    words.append(self._special_rev[i])
+                continue
+            w = self._words.get(i)
+            if w is None or self._word_id(w) != i:
+                w = f"t{i}"
+            words.append(w)
+        return " ".join(words)
+
+
+class HFTokenizer(BaseTokenizer):
+    def __init__(self, path: Path):
+        from tokenizers import Tokenizer
+
+        self._tok = Tokenizer.from_file(str(path / "tokenizer.json"))
+        self.vocab_size = self._tok.get_vocab_size()
+        cfg = {}
+        if (path / "tokenizer_config.json").exists():
+            with open(path / "tokenizer_config.json") as f:
+                cfg = json.load(f)
+        self.chat_template = cfg.get("chat_template")
+
+        def tok_id(key, default):
+            t = cfg.get(key)
+            if isinstance(t, dict):
+                t = t.get("content")
+            if isinstance(t, str):
+                i = self._tok.token_to_id(t)
+                if i is not None:
+                    return i
+            return default
+
+        self.bos_token_id = tok_id("bos_token", None)
+        self.eos_token_id = tok_id("eos_token", 2)
+        gen = path / "generation_config.json"
+        if gen.exists():
+            with open(gen) as f:
+                e = json.load(f).get("eos_token_id")
+            if isinstance(e, list):
+                e = e[0]
+            if isinstance(e, int):
+                self.eos_token_id = e
+
+    def encode(self, text: str, add_special_tokens: bool = True) -> list[int]:
+        return self._tok.encode(text, add_special_tokens=add_special_tokens).ids
+
+    def decode(self, ids: list[int], skip_special_tokens: bool = True) -> str:
+        return self._tok.decode(ids, skip_special_tokens=skip_special_tokens)
+
+
+def load_tokenizer(ckpt_dir: Path | None, vocab_size: int, chat_template_file: str | None = None):
+    tok: BaseTokenizer
+    if ckpt_dir is not None and (Path(ckpt_dir) / "tokenizer.json").exists():
+        tok = HFTokenizer(Path(ckpt_dir))
+    else:
+        tok = SyntheticTokenizer(vocab_size)
+    if chat_template_file:
+        tok.chat_template = Path(chat_template_file).read_text()
+    return tok
+
+
+class IncrementalDetokenizer:
+    """Streams text for a growing id list without re-decoding the whole sequence."""
+
+    def __init__(self, tokenizer: BaseTokenizer):
+        self.tok = tokenizer
+        self.ids: list[int] = []
+        self.prefix = 0
+        self.read = 0
+        self.text = ""
+
+    def push(self, new_ids: list[int]) -> str:
+        self.ids.extend(new_ids)
+        if isinstance(self.tok, SyntheticTokenizer):
+            piece = self.tok.decode(new_ids)
+            if not piece:
+                return ""
+            delta = (" " if self.text else "") + piece
+            self.text += delta
+            return delta
+        prefix_text = self.tok.decode(self.ids[self.prefix:self.read])
+        full = self.tok.decode(self.ids[self.prefix:])
+        if len(full) > len(prefix_text) and not full.endswith("�"):
+            delta = full[len(prefix_text):]
+            self.prefix = self.read
+            self.read = len(self.ids)
+            self.text += delta
+            return delta
+        return ""

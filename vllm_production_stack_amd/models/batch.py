@@ -1,0 +1,36 @@
+"""Device-side description of one engine step (a mixed batch).
+
+Token rows are ordered [decode rows | prefill rows]: the first ``num_decode`` rows are
+one-token continuations (served by the decode kernel, HIP-graph capturable), the rest
+are prompt chunks of ``num_prefill_seqs`` sequences (served by the prefill kernel).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+
+@dataclass
+class BatchMeta:
+    positions: torch.Tensor  # int32 [T]
+    slots: torch.Tensor  # int64 [T]  page*64 + offset, -1 = do not cache
+    num_decode: int = 0
+    # decode part
+    dec_block_tables: torch.Tensor | None = None  # int32 [num_decode, max_pages]
+    dec_ctx_lens: torch.Tensor | None = None  # int32 [num_decode]  (includes the new token)
+    dec_num_splits: int = 1
+    dec_ws_o: torch.Tensor | None = None
+    dec_ws_ml: torch.Tensor | None = None
+    # prefill part
+    num_prefill_seqs: int = 0
+    pre_block_tables: torch.Tensor | None = None  # int32 [num_prefill_seqs, max_pages]
+    pre_cu_q: torch.Tensor | None = None  # int32 [num_prefill_seqs + 1], rows relative to prefill part
+    pre_ctx_lens: torch.Tensor | None = None  # int32 [num_prefill_seqs]
+    pre_tile_seq: torch.Tensor | None = None
+    pre_tile_q0: torch.Tensor | None = None
+    # rows whose logits are needed (last row of every sequence that samples this step)
+    logits_rows: torch.Tensor | None = None  # int64 [num_out]
+    # per-row LoRA slot (-1 = base model), only when adapters are active
+    lora_slots: torch.Tensor | None = None
