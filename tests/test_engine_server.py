@@ -1,0 +1,170 @@
+"""HTTP contract of an engine replica (CPU, tiny random-init model)."""
+
+import asyncio
+import json
+
+import aiohttp
+import pytest
+
+from vllm_production_stack_amd.engine.async_engine import AsyncLLMEngine
+from vllm_production_stack_amd.engine.config import EngineConfig
+from vllm_production_stack_amd.engine.llm_engine import LLMEngine
+from vllm_production_stack_amd.engine.server import serve
+
+
+def run(coro):
+    return asyncio.run(coro)
+
+
+async def _with_server(fn, **cfg_kw):
+    cfg = EngineConfig(model="tiny-llama", device="cpu", dtype="float32", max_model_len=512,
+                       max_num_seqs=8, num_gpu_blocks_override=64, **cfg_kw)
+    eng = LLMEngine(cfg)
+    ae = AsyncLLMEngine(eng)
+    ae.start(asyncio.get_running_loop())
+    runner = await serve(ae, "127.0.0.1", 0)
+    port = runner.addresses[0][1]
+    try:
+        async with aiohttp.ClientSession(base_url=f"http://127.0.0.1:{port}") as s:
+            return await fn(s, eng)
+    finally:
+        await runner.cleanup()
+        ae.stop()
+
+
+def test_models_health_metrics_version():
+    async def fn(s, eng):
+        async with s.get("/health") as r:
+            assert r.status == 200
+        async with s.get("/v1/models") as r:
+            d = await r.json()
+            assert d["object"] == "list" and d["data"][0]["id"] == "tiny-llama"
+            assert d["data"][0]["parent"] is None and d["data"][0]["owned_by"] == "vllm"
+        async with s.get("/version") as r:
+            assert "version" in await r.json()
+        async with s.get("/metrics") as r:
+            text = await r.text()
+            for name in ("vllm:num_requests_running", "vllm:num_requests_waiting",
+                         "vllm:gpu_cache_usage_perc", "vllm:gpu_prefix_cache_hit_rate",
+                         "vllm:gpu_prefix_cache_hits_total", "vllm:gpu_prefix_cache_queries_total",
+                         "vllm:time_to_first_token_seconds", "vllm:e2e_request_latency_seconds",
+                         "vllm:time_per_output_token_seconds", "vllm:num_requests_swapped"):
+                assert name in text, name
+    run(_with_server(fn))
+
+
+def test_chat_completion_non_stream_and_stream_agree():
+    async def fn(s, eng):
+        body = {"model": "tiny-llama", "messages": [{"role": "user", "content": "hello there"}],
+                "max_tokens": 8, "temperature": 0, "ignore_eos": True}
+        async with s.post("/v1/chat/completions", json=body) as r:
+            assert r.status == 200
+            d = await r.json()
+        assert d["object"] == "chat.completion"
+        assert d["usage"]["completion_tokens"] == 8
+        text = d["choices"][0]["message"]["content"]
+        body["stream"] = True
+        body["stream_options"] = {"include_usage": True}
+        pieces, usage, done = [], None, False
+        async with s.post("/v1/chat/completions", json=body) as r:
+            assert r.headers["Content-Type"].startswith("text/event-stream")
+            async for line in r.content:
+                line = line.decode().strip()
+                if not line.startswith("data: "):
+                    continue
+                if line == "data: [DONE]":
+                    done = True
+                    continue
+                ev = json.loads(line[6:])
+                if ev.get("usage"):
+                    usage = ev["usage"]
+                for c in ev["choices"]:
+                    pieces.append(c["delta"].get("content") or "")
+        assert done and usage["completion_tokens"] == 8
+        assert "".join(pieces) == text
+    run(_with_server(fn))
+
+
+def test_completions_tokenize_detokenize_roundtrip():
+    async def fn(s, eng):
+        async with s.post("/v1/completions", json={"model": "tiny-llama", "prompt": "a b c",
+                                                    "max_tokens": 4, "temperature": 0,
+                                                    "ignore_eos": True}) as r:
+            d = await r.json()
+            assert d["object"] == "text_completion" and d["usage"]["completion_tokens"] == 4
+            gen = d["choices"][0]["text"]
+        async with s.post("/tokenize", json={"prompt": gen, "add_special_tokens": False}) as r:
+            toks = (await r.json())["tokens"]
+            assert len(toks) == 4
+        async with s.post("/detokenize", json={"tokens": toks}) as r:
+            assert (await r.json())["prompt"] == gen
+    run(_with_server(fn))
+
+
+def test_errors_unknown_model_and_too_long():
+    async def fn(s, eng):
+        async with s.post("/v1/completions", json={"model": "nope", "prompt": "x"}) as r:
+            assert r.status == 404
+        async with s.post("/v1/completions", json={"model": "tiny-llama",
+                                                    "prompt": "hi " * 600}) as r:
+            assert r.status == 400
+    run(_with_server(fn))
+
+
+def test_api_key_required():
+    async def fn(s, eng):
+        async with s.get("/v1/models") as r:
+            assert r.status == 401
+        async with s.get("/v1/models", headers={"Authorization": "Bearer sk"}) as r:
+            assert r.status == 200
+        async with s.get("/health") as r:
+            assert r.status == 200
+    run(_with_server(fn, api_key="sk"))
+
+
+def test_sleep_wake_cycle():
+    async def fn(s, eng):
+        async with s.get("/is_sleeping") as r:
+            assert (await r.json()) == {"is_sleeping": False}
+        async with s.post("/sleep?level=1") as r:
+            assert r.status == 200
+        async with s.get("/is_sleeping") as r:
+            assert (await r.json())["is_sleeping"] is True
+        async with s.post("/v1/completions", json={"model": "tiny-llama", "prompt": "x"}) as r:
+            assert r.status == 503
+        async with s.post("/wake_up") as r:
+            assert r.status == 200
+        async with s.post("/v1/completions", json={"model": "tiny-llama", "prompt": "x",
+                                                    "max_tokens": 2}) as r:
+            assert r.status == 200
+    run(_with_server(fn, enable_sleep_mode=True))
+
+
+def test_embeddings_score_rerank():
+    async def fn(s, eng):
+        async with s.post("/v1/embeddings", json={"model": "tiny-llama", "input": ["a b", "c d e"]}) as r:
+            d = await r.json()
+            assert len(d["data"]) == 2 and len(d["data"][0]["embedding"]) == 256
+        async with s.post("/v1/score", json={"model": "tiny-llama", "text_1": "q",
+                                              "text_2": ["a", "b"]}) as r:
+            assert len((await r.json())["data"]) == 2
+        async with s.post("/v1/rerank", json={"model": "tiny-llama", "query": "q",
+                                               "documents": ["a", "b", "c"], "top_n": 2}) as r:
+            assert len((await r.json())["results"]) == 2
+    run(_with_server(fn))
+
+
+def test_stop_string_truncates():
+    async def fn(s, eng):
+        body = {"model": "tiny-llama", "prompt": "x y", "max_tokens": 12, "temperature": 0,
+                "ignore_eos": True}
+        async with s.post("/v1/completions", json=body) as r:
+            full = (await r.json())["choices"][0]["text"]
+        words = full.split(" ")
+        i = next(k for k in range(1, len(words)) if words[k] not in " ".join(words[:k]))
+        body["stop"] = [words[i]]
+        async with s.post("/v1/completions", json=body) as r:
+            d = await r.json()
+        assert d["choices"][0]["text"] == " ".join(words[:i]) + " "
+        assert d["choices"][0]["finish_reason"] == "stop"
+    run(_with_server(fn))

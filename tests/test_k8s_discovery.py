@@ -1,0 +1,138 @@
+"""Kubernetes service discovery against a fake API server (watch streams over HTTP)."""
+
+import asyncio
+import json
+
+from aiohttp import web
+
+from vllm_production_stack_amd.router.discovery import (K8sPodIPServiceDiscovery,
+                                                         K8sServiceNameServiceDiscovery)
+from vllm_production_stack_amd.router.k8s_client import K8sClient
+from vllm_production_stack_amd.testing.fake_engine import FakeEngine
+
+
+class FakeKubeAPI:
+    def __init__(self):
+        self.queue: asyncio.Queue = asyncio.Queue()
+        self.patches = []
+        self.endpoints = {}
+        self.selectors = []
+        app = web.Application()
+        app.router.add_get("/api/v1/namespaces/{ns}/pods", self.watch)
+        app.router.add_get("/api/v1/namespaces/{ns}/services", self.watch)
+        app.router.add_get("/api/v1/namespaces/{ns}/endpoints/{name}", self.get_endpoints)
+        app.router.add_patch("/api/v1/namespaces/{ns}/pods/{name}", self.patch)
+        self.app = app
+
+    async def watch(self, request):
+        assert request.query.get("watch") == "true"
+        self.selectors.append(request.query.get("labelSelector"))
+        resp = web.StreamResponse(headers={"Content-Type": "application/json"})
+        await resp.prepare(request)
+        while True:
+            ev = await self.queue.get()
+            if ev is None:
+                break
+            await resp.write(json.dumps(ev).encode() + b"\n")
+        return resp
+
+    async def get_endpoints(self, request):
+        return web.json_response(self.endpoints.get(request.match_info["name"], {"subsets": []}))
+
+    async def patch(self, request):
+        self.patches.append((request.match_info["name"], await request.json()))
+        return web.json_response({})
+
+    async def start(self):
+        self.runner = web.AppRunner(self.app, access_log=None)
+        await self.runner.setup()
+        site = web.TCPSite(self.runner, "127.0.0.1", 0)
+        await site.start()
+        self.url = f"http://127.0.0.1:{self.runner.addresses[0][1]}"
+        return self
+
+
+def pod(name, ip, ready=True, labels=None, terminating=False, sleep_mode=False):
+    meta = {"name": name, "labels": labels or {}}
+    if terminating:
+        meta["deletionTimestamp"] = "2026-01-01T00:00:00Z"
+    return {"metadata": meta,
+            "spec": {"containers": [{"name": "vllm", "command": ["vllm", "serve", "m"] +
+                                     (["--enable-sleep-mode"] if sleep_mode else [])}]},
+            "status": {"podIP": ip, "containerStatuses": [{"ready": ready}]}}
+
+
+async def wait_for(cond, timeout=3.0):
+    for _ in range(int(timeout / 0.05)):
+        if cond():
+            return True
+        await asyncio.sleep(0.05)
+    return cond()
+
+
+def test_pod_ip_discovery_lifecycle():
+    async def go():
+        api = await FakeKubeAPI().start()
+        eng = await FakeEngine(model="m", lora=["adapter-1"]).start()
+        sd = K8sPodIPServiceDiscovery(namespace="default", port=eng.port, label_selector="app=x",
+                                      client=K8sClient(api=api.url))
+        await sd.start()
+        try:
+            await api.queue.put({"type": "ADDED", "object": pod("p1", "127.0.0.1", labels={"model": "llama"}, sleep_mode=True)})
+            assert await wait_for(lambda: len(sd.get_endpoint_info()) == 1)
+            ep = sd.get_endpoint_info()[0]
+            assert ep.url == eng.url and ep.model_label == "llama" and ep.pod_name == "p1"
+            assert set(ep.model_names) == {"m", "adapter-1"}
+            assert ep.model_info["adapter-1"].parent == "m" and ep.get_adapters() == ["adapter-1"]
+            assert ep.sleep is False and api.selectors[0] == "app=x"
+            first_id = ep.Id
+            # not-ready -> dropped; ready again -> same deterministic id
+            await api.queue.put({"type": "MODIFIED", "object": pod("p1", "127.0.0.1", ready=False)})
+            assert await wait_for(lambda: len(sd.get_endpoint_info()) == 0)
+            await api.queue.put({"type": "MODIFIED", "object": pod("p1", "127.0.0.1")})
+            assert await wait_for(lambda: len(sd.get_endpoint_info()) == 1)
+            assert sd.get_endpoint_info()[0].Id == first_id
+            await api.queue.put({"type": "MODIFIED", "object": pod("p1", "127.0.0.1", terminating=True)})
+            assert await wait_for(lambda: len(sd.get_endpoint_info()) == 0)
+            await api.queue.put({"type": "ADDED", "object": pod("p2", "127.0.0.1")})
+            assert await wait_for(lambda: len(sd.get_endpoint_info()) == 1)
+            await sd.set_sleep_label("p2", True)
+            assert api.patches[-1] == ("p2", {"metadata": {"labels": {"sleeping": "true"}}})
+            assert sd.get_endpoint_info()[0].sleep is True
+            await api.queue.put({"type": "DELETED", "object": pod("p2", "127.0.0.1")})
+            assert await wait_for(lambda: len(sd.get_endpoint_info()) == 0)
+            assert sd.get_health()
+            # the watch stream ending is survived: the watcher reconnects
+            await api.queue.put(None)
+            await asyncio.sleep(0.8)
+            await api.queue.put({"type": "ADDED", "object": pod("p3", "127.0.0.1")})
+            assert await wait_for(lambda: len(sd.get_endpoint_info()) == 1)
+        finally:
+            await sd.close()
+            await eng.stop()
+            await api.runner.cleanup()
+    asyncio.run(go())
+
+
+def test_service_name_discovery():
+    async def go():
+        api = await FakeKubeAPI().start()
+        eng = await FakeEngine(model="m").start()
+        sd = K8sServiceNameServiceDiscovery(namespace="ns", port=eng.port, client=K8sClient(api=api.url))
+        await sd.start()
+        try:
+            api.endpoints["localhost"] = {"subsets": [{"addresses": [{"ip": "10.0.0.1"}]}]}
+            svc = {"metadata": {"name": "localhost", "labels": {"model": "decode"}}, "spec": {}}
+            await api.queue.put({"type": "ADDED", "object": svc})
+            assert await wait_for(lambda: len(sd.get_endpoint_info()) == 1)
+            ep = sd.get_endpoint_info()[0]
+            assert ep.url == f"http://localhost:{eng.port}" and ep.service_name == "localhost"
+            assert ep.model_label == "decode"
+            api.endpoints["localhost"] = {"subsets": []}
+            await api.queue.put({"type": "MODIFIED", "object": svc})
+            assert await wait_for(lambda: len(sd.get_endpoint_info()) == 0)
+        finally:
+            await sd.close()
+            await eng.stop()
+            await api.runner.cleanup()
+    asyncio.run(go())

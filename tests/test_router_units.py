@@ -1,0 +1,319 @@
+"""Router unit tests with duck-typed fakes (the routing interface is structural)."""
+
+import asyncio
+import json
+import random
+import time
+
+import pytest
+
+from vllm_production_stack_amd.router import config as rconfig
+from vllm_production_stack_amd.router.feature_gates import FeatureGates
+from vllm_production_stack_amd.router.native import HashRing, HashTrie, native_available
+from vllm_production_stack_amd.router.pii import PIIType, RegexAnalyzer
+from vllm_production_stack_amd.router.routing import (DisaggregatedPrefillRouter, KvawareRouter,
+                                                       PrefixAwareRouter, RoundRobinRouter,
+                                                       SessionRouter, extract_prompt_text)
+from vllm_production_stack_amd.router.stats import (EngineStats, MovingAverageMonitor,
+                                                     RequestStatsMonitor)
+from vllm_production_stack_amd.router.utils import (ModelType, parse_static_aliases,
+                                                     parse_static_urls, update_content_length,
+                                                     validate_url)
+
+
+class EP:
+    def __init__(self, url, label="default"):
+        self.url = url
+        self.model_label = label
+
+
+class RS:
+    def __init__(self, qps, prefill=0, decoding=0):
+        self.qps = qps
+        self.in_prefill_requests = prefill
+        self.in_decoding_requests = decoding
+
+
+class Req:
+    def __init__(self, headers=None):
+        self.headers = headers or {}
+
+
+def test_native_core_is_built():
+    assert native_available()
+
+
+# ---------------------------------------------------------------- round robin
+def test_roundrobin_even_distribution():
+    r = RoundRobinRouter()
+    eps = [EP(f"http://e{i}") for i in range(5)]
+    counts = {}
+    for _ in range(103):
+        u = r.route_request(eps, {}, {}, Req())
+        counts[u] = counts.get(u, 0) + 1
+    assert max(counts.values()) - min(counts.values()) <= 1
+
+
+def test_roundrobin_order_independent_of_list_order_and_membership_change():
+    r = RoundRobinRouter()
+    eps = [EP("http://b"), EP("http://a"), EP("http://c")]
+    seq = [r.route_request(eps, {}, {}, Req()) for _ in range(3)]
+    assert seq == ["http://a", "http://b", "http://c"]
+    eps2 = [EP("http://a"), EP("http://c")]
+    got = {r.route_request(eps2, {}, {}, Req()) for _ in range(4)}
+    assert got == {"http://a", "http://c"}
+
+
+# ---------------------------------------------------------------- session
+def test_session_stickiness_and_qps_fallback():
+    r = SessionRouter("x-user-id")
+    eps = [EP(f"http://e{i}") for i in range(4)]
+    first = r.route_request(eps, {}, {}, Req({"x-user-id": "alice"}))
+    for _ in range(20):
+        assert r.route_request(eps, {}, {}, Req({"x-user-id": "alice"})) == first
+    stats = {"http://e0": RS(5), "http://e1": RS(1), "http://e2": RS(3), "http://e3": RS(9)}
+    assert r.route_request(eps, {}, stats, Req()) == "http://e1"
+    del stats["http://e2"]
+    assert r.route_request(eps, {}, stats, Req()) == "http://e2"  # no stats yet wins
+
+
+@pytest.mark.parametrize("force_python", [False, True])
+def test_consistent_hash_minimal_remap(force_python):
+    ring = HashRing(force_python=force_python)
+    nodes = [f"http://e{i}" for i in range(5)]
+    for n in nodes:
+        ring.add_node(n)
+    keys = [f"user-{i}" for i in range(2000)]
+    before = {k: ring.get_node(k) for k in keys}
+    shares = {n: sum(1 for v in before.values() if v == n) for n in nodes}
+    assert min(shares.values()) > 200  # roughly balanced
+    ring.remove_node("http://e2")
+    after = {k: ring.get_node(k) for k in keys}
+    for k in keys:
+        if before[k] != "http://e2":
+            assert after[k] == before[k]  # only the removed node's keys move
+    ring.add_node("http://e2")
+    assert {k: ring.get_node(k) for k in keys} == before
+
+
+def test_native_and_python_ring_agree():
+    a, b = HashRing(), HashRing(force_python=True)
+    for n in ("http://x:1", "http://y:2", "http://z:3"):
+        a.add_node(n)
+        b.add_node(n)
+    for i in range(500):
+        assert a.get_node(f"k{i}") == b.get_node(f"k{i}")
+
+
+# ---------------------------------------------------------------- prefix trie
+@pytest.mark.parametrize("force_python", [False, True])
+def test_hashtrie_longest_prefix(force_python):
+    t = HashTrie(chunk_size=4, force_python=force_python)
+    t.insert("aaaabbbbcccc", "e1")
+    t.insert("aaaabbbbdddd", "e2")
+    t.insert("aaaaxxxx", "e3")
+    allp = {"e1", "e2", "e3"}
+    assert t.longest_prefix_match("aaaabbbbcccczzzz", allp) == (12, {"e1"})
+    assert t.longest_prefix_match("aaaabbbbqqqq", allp) == (8, {"e1", "e2"})
+    assert t.longest_prefix_match("aaaa", allp) == (4, allp)
+    assert t.longest_prefix_match("zzzz", allp) == (0, allp)
+    # unavailable endpoints are skipped: the match stops where the available set empties
+    assert t.longest_prefix_match("aaaabbbbcccc", {"e3"}) == (4, {"e3"})
+    t.remove_endpoint("e1")
+    assert t.longest_prefix_match("aaaabbbbcccc", allp) == (8, {"e2"})
+
+
+def test_hashtrie_native_python_agree_on_unicode():
+    a, b = HashTrie(chunk_size=3), HashTrie(chunk_size=3, force_python=True)
+    s = "héllo wörld ✓✓✓ 你好世界 end"
+    for t in (a, b):
+        t.insert(s, "e1")
+    for q in (s, s[:7], s[:4] + "zzz", "你好"):
+        assert a.longest_prefix_match(q, {"e1", "e2"}) == b.longest_prefix_match(q, {"e1", "e2"})
+
+
+def test_hashtrie_bounded_memory():
+    t = HashTrie(chunk_size=4, max_nodes=2000)
+    rnd = random.Random(0)
+    for i in range(3000):
+        t.insert("".join(rnd.choice("abcdefgh") for _ in range(40)), "e1")
+    assert t.node_count() <= 2100
+
+
+def test_prefixaware_router_sticks_to_prefix():
+    r = PrefixAwareRouter()
+    eps = [EP(f"http://e{i}") for i in range(4)]
+    base = "x" * 300
+    first = r.route_request(eps, {}, {}, Req(), {"prompt": base})
+    for i in range(10):
+        assert r.route_request(eps, {}, {}, Req(), {"prompt": base + f" turn {i}" * 20}) == first
+    chat = {"messages": [{"role": "system", "content": "s" * 200},
+                         {"role": "user", "content": [{"type": "text", "text": "hi"},
+                                                      {"type": "image_url", "image_url": {}}]}]}
+    assert extract_prompt_text(chat) == "s" * 200 + "\nhi"
+    u = r.route_request(eps, {}, {}, Req(), chat)
+    assert r.route_request(eps, {}, {}, Req(), chat) == u
+
+
+# ---------------------------------------------------------------- kvaware / pd
+def test_kvaware_routes_to_holder_else_session_fallback():
+    from vllm_production_stack_amd.controller import KVController
+    from vllm_production_stack_amd.engine.block_manager import chain_hashes
+
+    ctrl = KVController()
+    ctrl.register("inst-a", "http://e0")
+    ctrl.register("inst-b", "http://e1")
+    toks = list(range(100, 100 + 640))
+    ctrl.admit("inst-b", chain_hashes(toks))
+    r = KvawareRouter(ctrl, session_key="x-user-id", kv_aware_threshold=100, controller_port=0,
+                      tokenize=lambda rj: rj["tokens"])
+    eps = [EP("http://e0"), EP("http://e1")]
+    run = asyncio.run
+    assert run(r.route_request(eps, {}, {}, Req(), {"tokens": toks + [1, 2, 3]})) == "http://e1"
+    # nothing cached for this prompt -> session hashing
+    other = list(range(5000, 5640))
+    u1 = run(r.route_request(eps, {}, {}, Req({"x-user-id": "bob"}), {"tokens": other}))
+    u2 = run(r.route_request(eps, {}, {}, Req({"x-user-id": "bob"}), {"tokens": other}))
+    assert u1 == u2
+    # match shorter than len - threshold -> fallback (QPS: e0 has no stats)
+    long = toks + list(range(9000, 9000 + 2000))
+    assert run(r.route_request(eps, {}, {"http://e1": RS(1)}, Req(), {"tokens": long})) == "http://e0"
+    ctrl.evict("inst-b", chain_hashes(toks)[5:])
+    assert ctrl.lookup(chain_hashes(toks)) == {"inst-b": 5 * 64}
+
+
+def test_disaggregated_router_balances_pools():
+    r = DisaggregatedPrefillRouter(["prefill"], ["decode"])
+    eps = [EP("http://p0", "prefill"), EP("http://p1", "prefill")] + \
+          [EP(f"http://d{i}", "decode") for i in range(3)]
+    stats = {"http://p0": RS(1, prefill=3), "http://p1": RS(1, prefill=0),
+             "http://d0": RS(1, decoding=5), "http://d1": RS(1, decoding=1), "http://d2": RS(1, decoding=4)}
+    assert r.route_request(eps, {}, stats, Req(), {"max_tokens": 1}) == "http://p1"
+    assert r.route_request(eps, {}, stats, Req(), {"max_tokens": 100}) == "http://d1"
+    seen = {r.route_request(eps, {}, {}, Req(), {"max_tokens": 50}) for _ in range(9)}
+    assert seen == {"http://d0", "http://d1", "http://d2"}
+    with pytest.raises(ValueError):
+        DisaggregatedPrefillRouter(["x"], ["y"]).route_request(eps, {}, {}, Req(), {"max_tokens": 1})
+
+
+# ---------------------------------------------------------------- stats
+def test_moving_average_window():
+    m = MovingAverageMonitor(10)
+    m.update(0, 1)
+    m.update(5, 3)
+    assert m.get_sum() == 4 and m.get_average() == 2
+    m.update(12, 5)
+    assert m.get_sum() == 8
+    m.update_no_value(30)
+    assert m.get_sum() == 0 and m.get_average() == -1
+
+
+def test_request_stats_lifecycle_and_pruning():
+    mon = RequestStatsMonitor(60)
+    t = 1000.0
+    mon.on_new_request("http://e", "r1", t)
+    mon.on_new_request("http://e", "r2", t + 1)
+    s = mon.get_request_stats(t + 1)["http://e"]
+    assert s.in_prefill_requests == 2 and s.qps == pytest.approx(2 / 60)
+    mon.on_request_response("http://e", "r1", t + 2)
+    mon.on_request_chunk("http://e", "r1", t + 2.5)
+    mon.on_request_chunk("http://e", "r1", t + 3.0)
+    s = mon.get_request_stats(t + 3)["http://e"]
+    assert s.in_prefill_requests == 1 and s.in_decoding_requests == 1
+    assert s.ttft == pytest.approx(2.0) and s.avg_itl == pytest.approx(0.5)
+    mon.on_request_complete("http://e", "r1", t + 4)
+    s = mon.get_request_stats(t + 4)["http://e"]
+    assert s.finished_requests == 1 and s.avg_latency == pytest.approx(4.0)
+    assert s.avg_decoding_length == pytest.approx(2.0)
+    mon.on_request_failed("http://e", "r2", t + 5)
+    assert mon.inflight == {}
+    assert mon.get_request_stats(t + 5)["http://e"].in_prefill_requests == 0
+
+
+def test_engine_stats_parse():
+    text = """# HELP vllm:num_requests_running x
+# TYPE vllm:num_requests_running gauge
+vllm:num_requests_running{model_name="m"} 3.0
+vllm:num_requests_waiting{model_name="m"} 7.0
+vllm:gpu_prefix_cache_hit_rate{model_name="m"} 0.25
+vllm:gpu_prefix_cache_hits_total{model_name="m"} 50.0
+vllm:gpu_prefix_cache_queries_total{model_name="m"} 200.0
+vllm:gpu_cache_usage_perc{model_name="m"} 0.4
+"""
+    s = EngineStats.from_vllm_scrape(text)
+    assert (s.num_running_requests, s.num_queuing_requests) == (3, 7)
+    assert s.gpu_prefix_cache_hit_rate == 0.25 and s.gpu_cache_usage_perc == 0.4
+    assert s.gpu_prefix_cache_hits_total == 50 and s.gpu_prefix_cache_queries_total == 200
+
+
+# ---------------------------------------------------------------- config / utils
+def test_parse_args_and_validation(tmp_path):
+    a = rconfig.parse_args(["--service-discovery", "static", "--static-backends", "http://a:1,http://b:2",
+                            "--static-models", "m,m", "--routing-logic", "roundrobin"])
+    assert a.port == 8001 and a.engine_stats_interval == 30 and a.kv_aware_threshold == 2000
+    with pytest.raises(ValueError):
+        rconfig.parse_args(["--service-discovery", "static", "--routing-logic", "roundrobin"])
+    with pytest.raises(ValueError):
+        rconfig.parse_args(["--service-discovery", "static", "--static-backends", "http://a:1",
+                            "--static-models", "m", "--routing-logic", "session"])
+    with pytest.raises(ValueError):
+        rconfig.parse_args(["--service-discovery", "static", "--static-backends", "http://a:1",
+                            "--static-models", "m", "--routing-logic", "roundrobin",
+                            "--static-backend-health-checks", "--static-model-types", "bogus"])
+    y = tmp_path / "cfg.yaml"
+    y.write_text("""
+service_discovery: static
+routing_logic: session
+session_key: x-user-id
+static_models:
+  llama:
+    static_backends: [http://a:1, http://b:2]
+    static_model_type: chat
+  emb:
+    static_backends: [http://c:3]
+    static_model_type: embeddings
+static_aliases:
+  gpt4: llama
+""")
+    a = rconfig.parse_args(["--dynamic-config-yaml", str(y)])
+    assert a.static_backends == "http://a:1,http://b:2,http://c:3"
+    assert a.static_models == "llama,llama,emb"
+    assert a.static_model_types == "chat,chat,embeddings"
+    assert a.static_aliases == "gpt4:llama" and a.session_key == "x-user-id"
+    d = rconfig.DynamicRouterConfig.from_file(str(y))
+    assert d.routing_logic == "session" and d.static_models == "llama,llama,emb"
+    j = tmp_path / "cfg.json"
+    j.write_text(json.dumps({"service_discovery": "static", "routing_logic": "roundrobin",
+                             "static_backends": "http://z:9", "static_models": "m"}))
+    a = rconfig.parse_args(["--dynamic-config-json", str(j), "--routing-logic", "prefixaware"])
+    assert a.routing_logic == "prefixaware" and a.static_backends == "http://z:9"
+
+
+def test_utils():
+    assert validate_url("http://localhost:8000") and validate_url("https://a.b-c.d/v1")
+    assert not validate_url("ftp://x") and not validate_url("localhost:8000")
+    assert parse_static_urls("http://a:1, bad ,http://b:2") == ["http://a:1", "http://b:2"]
+    assert parse_static_aliases("x:y,z:w") == {"x": "y", "z": "w"}
+    h = update_content_length({"content-length": "5", "A": "b"}, b"1234567")
+    assert h["Content-Length"] == "7" and "content-length" not in h
+    for t in ModelType.get_all_fields():
+        assert ModelType.get_url(t).startswith("/v1/")
+        assert ModelType.get_test_payload(t)
+
+
+def test_feature_gates():
+    g = FeatureGates("SemanticCache=true,PIIDetection=false")
+    assert g.is_enabled("SemanticCache") and not g.is_enabled("PIIDetection")
+    with pytest.raises(ValueError):
+        FeatureGates("Nope=true")
+    with pytest.raises(ValueError):
+        FeatureGates("SemanticCache")
+
+
+def test_pii_regex_analyzer():
+    a = RegexAnalyzer()
+    r = a.analyze("mail me at bob@example.com or call 415-555-1234, ssn 123-45-6789, "
+                  "card 4111 1111 1111 1111 from 10.1.2.3")
+    assert r.types == {PIIType.EMAIL, PIIType.PHONE, PIIType.SSN, PIIType.CREDIT_CARD, PIIType.IP_ADDRESS}
+    assert not a.analyze("the quick brown fox 1234 5678").has_pii
+    assert not a.analyze("card 4111 1111 1111 1112").has_pii  # Luhn fails

@@ -62,7 +62,7 @@ class LLMEngine:
     # ------------------------------------------------------------------ intake
     def add_request(self, prompt_ids: list[int], params: SamplingParams,
                     request_id: str | None = None, lora_name: str | None = None,
-                    kv_transfer_params: dict | None = None) -> Request:
+                    kv_transfer_params: dict | None = None, pooling: bool = False) -> Request:
         rid = request_id or uuid.uuid4().hex
         if len(prompt_ids) == 0:
             prompt_ids = [self.tokenizer.bos_token_id or 0]
@@ -71,7 +71,7 @@ class LLMEngine:
                 f"prompt has {len(prompt_ids)} tokens; the context limit is {self.max_model_len}")
         params.max_tokens = max(1, min(params.max_tokens, self.max_model_len - len(prompt_ids)))
         req = Request(rid, list(prompt_ids), params, lora_name=lora_name,
-                      kv_transfer_params=kv_transfer_params)
+                      kv_transfer_params=kv_transfer_params, pooling=pooling)
         if lora_name and self.lora_manager is not None:
             req.lora_slot = self.lora_manager.slot_of(lora_name)
         self.requests[rid] = req

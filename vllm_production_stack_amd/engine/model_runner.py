@@ -179,6 +179,9 @@ class ModelRunner:
         hidden = self.model.forward(ids, self.pool, meta)
         if not sample_seqs:
             return []
+        for i, s in enumerate(sample_seqs):
+            if s.req.pooling:
+                s.req.pooled = hidden[i].float().cpu()
         logits = self.model.compute_logits(hidden)
         toks, infos = self.sampler.sample(logits, [s.req for s in sample_seqs])
         return list(zip(sample_seqs, toks, infos))

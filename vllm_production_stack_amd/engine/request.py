@@ -64,6 +64,9 @@ class Request:
     # P/D disaggregation
     kv_transfer_params: dict | None = None
     load_event: object | None = None  # device event the first compute step must wait on
+    # pooling (embeddings / scoring) requests return the final hidden state instead of text
+    pooling: bool = False
+    pooled: object | None = None
     # streaming sink (set by the async engine)
     sink: object | None = None
     detok_offset: int = 0

@@ -1,0 +1,522 @@
+"""OpenAI-compatible HTTP front of one engine replica (aiohttp).
+
+Implements the endpoint, metric and auth contract the router, the LoRA operator and the
+probes of the reference consume from an engine process
+(/root/reference/src/vllm_router/routers/main_router.py:50-246,
+/root/reference/src/vllm_router/service_discovery.py:414-563,
+/root/reference/operator/internal/controller/loraadapter_controller.go:582-610).
+"""
+
+from __future__ import annotations
+
+import asyncio
+import json
+import logging
+import math
+import time
+import uuid
+
+from aiohttp import web
+
+from .. import __version__
+from .async_engine import AsyncLLMEngine
+from .request import SamplingParams
+from .tokenizer import IncrementalDetokenizer
+from .tools import parse_tool_calls
+
+log = logging.getLogger("vpsa.server")
+
+_OPEN_PATHS = {"/health", "/metrics", "/version", "/ping"}
+
+
+def _err(status: int, message: str, etype: str = "BadRequestError") -> web.Response:
+    return web.json_response(
+        {"object": "error", "message": message, "type": etype, "param": None, "code": status},
+        status=status)
+
+
+def _sampling_from_body(body: dict, default_max: int) -> SamplingParams:
+    mt = body.get("max_completion_tokens") or body.get("max_tokens") or default_max
+    stop = body.get("stop") or []
+    if isinstance(stop, str):
+        stop = [stop]
+    lp = body.get("logprobs")
+    if lp is True:
+        lp = body.get("top_logprobs") or 1
+    elif lp is False:
+        lp = None
+    return SamplingParams(
+        max_tokens=int(mt), temperature=float(body.get("temperature", 1.0) if body.get("temperature") is not None else 1.0),
+        top_p=float(body.get("top_p") or 1.0), top_k=int(body.get("top_k") or -1),
+        seed=body.get("seed"), stop=list(stop), stop_token_ids=list(body.get("stop_token_ids") or []),
+        ignore_eos=bool(body.get("ignore_eos", False)), logprobs=lp, n=int(body.get("n") or 1),
+        presence_penalty=float(body.get("presence_penalty") or 0.0),
+        frequency_penalty=float(body.get("frequency_penalty") or 0.0),
+        repetition_penalty=float(body.get("repetition_penalty") or 1.0),
+        min_tokens=int(body.get("min_tokens") or 0))
+
+
+class EngineServer:
+    def __init__(self, aengine: AsyncLLMEngine):
+        self.ae = aengine
+        self.engine = aengine.engine
+        self.cfg = self.engine.cfg
+        self.created = int(time.time())
+        self.app = web.Application(client_max_size=256 * 1024 * 1024, middlewares=[self._auth])
+        r = self.app.router
+        r.add_get("/health", self.health)
+        r.add_get("/ping", self.health)
+        r.add_get("/version", self.version)
+        r.add_get("/metrics", self.metrics)
+        r.add_get("/v1/models", self.models)
+        r.add_post("/v1/chat/completions", self.chat)
+        r.add_post("/v1/completions", self.completions)
+        r.add_post("/v1/embeddings", self.embeddings)
+        r.add_post("/tokenize", self.tokenize)
+        r.add_post("/detokenize", self.detokenize)
+        for p in ("/v1/rerank", "/rerank", "/v2/rerank"):
+            r.add_post(p, self.rerank)
+        for p in ("/v1/score", "/score"):
+            r.add_post(p, self.score)
+        r.add_post("/v1/audio/transcriptions", self.transcriptions)
+        r.add_post("/sleep", self.sleep)
+        r.add_post("/wake_up", self.wake_up)
+        r.add_get("/is_sleeping", self.is_sleeping)
+        r.add_post("/v1/load_lora_adapter", self.load_lora)
+        r.add_post("/v1/unload_lora_adapter", self.unload_lora)
+        r.add_post("/reset_prefix_cache", self.reset_prefix_cache)
+        r.add_get("/kv/lookup", self.kv_lookup)
+        r.add_post("/kv/lookup", self.kv_lookup)
+
+    # ------------------------------------------------------------------ middleware
+    @web.middleware
+    async def _auth(self, request: web.Request, handler):
+        key = self.cfg.api_key
+        if key and request.path not in _OPEN_PATHS:
+            if request.headers.get("Authorization", "") != f"Bearer {key}":
+                return web.json_response({"error": "Unauthorized"}, status=401)
+        return await handler(request)
+
+    # ------------------------------------------------------------------ small endpoints
+    async def health(self, request):
+        if not self.ae.healthy:
+            return web.Response(status=503)
+        return web.Response(status=200)
+
+    async def version(self, request):
+        return web.json_response({"version": __version__})
+
+    async def metrics(self, request):
+        return web.Response(body=self.engine.metrics.render(),
+                            headers={"Content-Type": "text/plain; version=0.0.4; charset=utf-8"})
+
+    def _model_cards(self) -> list[dict]:
+        base = {"id": self.cfg.model_name, "object": "model", "created": self.created,
+                "owned_by": "vllm", "root": self.cfg.model, "parent": None,
+                "max_model_len": self.engine.max_model_len}
+        cards = [base]
+        lm = self.engine.lora_manager
+        if lm is not None:
+            for name, path in lm.list_adapters():
+                cards.append({"id": name, "object": "model", "created": self.created,
+                              "owned_by": "vllm", "root": path, "parent": self.cfg.model_name})
+        return cards
+
+    async def models(self, request):
+        return web.json_response({"object": "list", "data": self._model_cards()})
+
+    def _resolve_model(self, name: str | None):
+        """-> (ok, lora_name)"""
+        if not name or name == self.cfg.model_name or name == self.cfg.model:
+            return True, None
+        lm = self.engine.lora_manager
+        if lm is not None and lm.has(name):
+            return True, name
+        return False, None
+
+    async def tokenize(self, request):
+        body = await request.json()
+        tok = self.engine.tokenizer
+        if "messages" in body:
+            ids = tok.encode_chat(body["messages"], body.get("add_generation_prompt", True))
+        else:
+            ids = tok.encode(body.get("prompt", ""), body.get("add_special_tokens", True))
+        return web.json_response({"count": len(ids), "max_model_len": self.engine.max_model_len,
+                                  "tokens": ids})
+
+    async def detokenize(self, request):
+        body = await request.json()
+        return web.json_response({"prompt": self.engine.tokenizer.decode(body.get("tokens", []))})
+
+    # ------------------------------------------------------------------ sleep mode
+    async def sleep(self, request):
+        if not self.cfg.enable_sleep_mode:
+            return _err(400, "sleep mode is not enabled (--enable-sleep-mode)")
+        level = int(request.query.get("level", "1"))
+        t0 = time.time()
+        freed = await self.ae.call(lambda: self.engine.sleep(level))
+        log.info("Sleep mode freed %.2f GiB memory; it took %.6f seconds to fall asleep.",
+                 freed / 2**30, time.time() - t0)
+        return web.Response(status=200)
+
+    async def wake_up(self, request):
+        if not self.cfg.enable_sleep_mode:
+            return _err(400, "sleep mode is not enabled (--enable-sleep-mode)")
+        await self.ae.call(self.engine.wake_up)
+        return web.Response(status=200)
+
+    async def is_sleeping(self, request):
+        return web.json_response({"is_sleeping": bool(self.engine.is_sleeping)})
+
+    async def reset_prefix_cache(self, request):
+        n = await self.ae.call(self.engine.bm.reset_prefix_cache)
+        return web.json_response({"released_pages": n})
+
+    async def kv_lookup(self, request):
+        """How many leading tokens of a prompt are resident in this replica's KV tiers."""
+        if request.method == "POST":
+            body = await request.json()
+        else:
+            body = dict(request.query)
+        tokens = body.get("tokens")
+        if tokens is None:
+            tokens = self.engine.tokenizer.encode(body.get("prompt", ""))
+        from .block_manager import PAGE, chain_hashes
+
+        hashes = chain_hashes(list(tokens))
+        n = self.engine.bm.peek_prefix(hashes)
+        if self.engine.connector is not None and n < len(hashes):
+            n += self.engine.connector.lookup(hashes[n:])
+        return web.json_response({"matched_tokens": n * PAGE, "total_tokens": len(tokens)})
+
+    # ------------------------------------------------------------------ LoRA
+    async def load_lora(self, request):
+        if not self.cfg.enable_lora:
+            return _err(400, "LoRA is not enabled (--enable-lora)")
+        body = await request.json()
+        name, path = body.get("lora_name"), body.get("lora_path")
+        if not name or not path:
+            return _err(400, "lora_name and lora_path are required")
+        lm = self.engine.lora_manager
+        if lm.has(name):
+            return _err(400, f"The lora adapter '{name}' has already been loaded.")
+        try:
+            await self.ae.call(lambda: lm.load(name, path))
+        except FileNotFoundError as e:
+            return _err(404, str(e), "NotFoundError")
+        except Exception as e:
+            return _err(400, f"failed to load adapter: {e}")
+        return web.Response(text=f"Success: LoRA adapter '{name}' added successfully.")
+
+    async def unload_lora(self, request):
+        if not self.cfg.enable_lora:
+            return _err(400, "LoRA is not enabled (--enable-lora)")
+        body = await request.json()
+        name = body.get("lora_name")
+        lm = self.engine.lora_manager
+        if not name or not lm.has(name):
+            return _err(404, f"The lora adapter '{name}' cannot be found.", "NotFoundError")
+        await self.ae.call(lambda: lm.unload(name))
+        return web.Response(text=f"Success: LoRA adapter '{name}' removed successfully.")
+
+    # ------------------------------------------------------------------ generation core
+    async def _run_text(self, rid, ids, params, lora, kvp=None):
+        """Collect a whole generation. -> (text, out_ids, finish_reason, usage dict)"""
+        detok = IncrementalDetokenizer(self.engine.tokenizer)
+        text = ""
+        out_ids: list[int] = []
+        reason = None
+        last = None
+        async for so in self.ae.generate(rid, ids, params, lora, kvp):
+            last = so
+            new = [t for t in so.new_token_ids if not (so.finished and so.finish_reason == "stop"
+                                                       and t in self.engine.eos_ids)]
+            out_ids.extend(so.new_token_ids)
+            text += detok.push(new)
+            hit = self._stop_hit(text, params.stop)
+            if hit is not None:
+                text = text[:hit]
+                reason = "stop"
+                break
+            if so.finished:
+                reason = so.finish_reason
+        usage = {"prompt_tokens": len(ids), "completion_tokens": len(out_ids),
+                 "total_tokens": len(ids) + len(out_ids)}
+        if last is not None and last.num_cached_tokens:
+            usage["prompt_tokens_details"] = {"cached_tokens": last.num_cached_tokens}
+        return text, out_ids, reason or "stop", usage
+
+    @staticmethod
+    def _stop_hit(text: str, stops: list[str]) -> int | None:
+        best = None
+        for s in stops:
+            if s:
+                i = text.find(s)
+                if i >= 0 and (best is None or i < best):
+                    best = i
+        return best
+
+    async def _stream(self, request, rid, ids, params, lora, kind, model, include_usage, kvp=None):
+        resp = web.StreamResponse(status=200, headers={
+            "Content-Type": "text/event-stream", "Cache-Control": "no-cache", "X-Request-Id": rid})
+        await resp.prepare(request)
+        created = int(time.time())
+        cid = ("chatcmpl-" if kind == "chat" else "cmpl-") + rid
+        obj = "chat.completion.chunk" if kind == "chat" else "text_completion"
+
+        def chunk(delta_text=None, finish=None, role=False, usage=None, choices=True):
+            d = {"id": cid, "object": obj, "created": created, "model": model}
+            if choices:
+                if kind == "chat":
+                    delta = {}
+                    if role:
+                        delta["role"] = "assistant"
+                        delta["content"] = ""
+                    if delta_text is not None:
+                        delta["content"] = delta_text
+                    d["choices"] = [{"index": 0, "delta": delta, "logprobs": None,
+                                     "finish_reason": finish}]
+                else:
+                    d["choices"] = [{"index": 0, "text": delta_text or "", "logprobs": None,
+                                     "finish_reason": finish}]
+            else:
+                d["choices"] = []
+            if usage is not None:
+                d["usage"] = usage
+            return b"data: " + json.dumps(d, separators=(",", ":")).encode() + b"\n\n"
+
+        detok = IncrementalDetokenizer(self.engine.tokenizer)
+        n_out = 0
+        text = ""
+        sent = 0
+        reason = None
+        cached = 0
+        try:
+            if kind == "chat":
+                await resp.write(chunk(role=True))
+            async for so in self.ae.generate(rid, ids, params, lora, kvp):
+                n_out += len(so.new_token_ids)
+                cached = so.num_cached_tokens
+                new = [t for t in so.new_token_ids
+                       if not (so.finished and so.finish_reason == "stop" and t in self.engine.eos_ids)]
+                text += detok.push(new)
+                hit = self._stop_hit(text, params.stop)
+                if hit is not None:
+                    text = text[:hit]
+                    reason = "stop"
+                elif so.finished:
+                    reason = so.finish_reason
+                # hold back a tail that could still turn into a stop string
+                hold = max((len(s) - 1 for s in params.stop), default=0) if reason is None else 0
+                upto = max(sent, len(text) - hold)
+                if upto > sent:
+                    await resp.write(chunk(delta_text=text[sent:upto]))
+                    sent = upto
+                if reason is not None:
+                    break
+            await resp.write(chunk(delta_text="" if kind == "chat" else "", finish=reason or "stop"))
+            if include_usage:
+                usage = {"prompt_tokens": len(ids), "completion_tokens": n_out,
+                         "total_tokens": len(ids) + n_out}
+                if cached:
+                    usage["prompt_tokens_details"] = {"cached_tokens": cached}
+                await resp.write(chunk(usage=usage, choices=False))
+            await resp.write(b"data: [DONE]\n\n")
+        except (ConnectionResetError, asyncio.CancelledError):
+            raise
+        except Exception as e:
+            log.exception("stream failed")
+            await resp.write(b"data: " + json.dumps({"error": str(e)}).encode() + b"\n\n")
+        await resp.write_eof()
+        return resp
+
+    async def _prepare(self, request, kind):
+        try:
+            body = await request.json()
+        except Exception:
+            return None, _err(400, "request body is not valid JSON")
+        ok, lora = self._resolve_model(body.get("model"))
+        if not ok:
+            return None, _err(404, f"The model `{body.get('model')}` does not exist.", "NotFoundError")
+        if self.engine.is_sleeping:
+            return None, _err(503, "engine is sleeping", "ServiceUnavailable")
+        tok = self.engine.tokenizer
+        try:
+            if kind == "chat":
+                msgs = body.get("messages")
+                if not isinstance(msgs, list) or not msgs:
+                    return None, _err(400, "'messages' must be a non-empty list")
+                ids = tok.encode_chat(msgs, True, body.get("tools"))
+            else:
+                prompt = body.get("prompt", "")
+                if isinstance(prompt, list) and prompt and isinstance(prompt[0], int):
+                    ids = list(prompt)
+                elif isinstance(prompt, list):
+                    ids = tok.encode(str(prompt[0]) if prompt else "")
+                else:
+                    ids = tok.encode(str(prompt))
+        except Exception as e:
+            return None, _err(400, f"failed to build prompt: {e}")
+        if len(ids) >= self.engine.max_model_len:
+            return None, _err(400, f"This model's maximum context length is {self.engine.max_model_len} "
+                                   f"tokens. However, you requested {len(ids)} prompt tokens.")
+        params = _sampling_from_body(body, 16 if kind == "completion" else self.engine.max_model_len)
+        rid = request.headers.get("X-Request-Id") or uuid.uuid4().hex
+        return (body, ids, params, lora, rid), None
+
+    async def chat(self, request):
+        prep, err = await self._prepare(request, "chat")
+        if err is not None:
+            return err
+        body, ids, params, lora, rid = prep
+        model = body.get("model") or self.cfg.model_name
+        kvp = body.get("kv_transfer_params")
+        if body.get("stream"):
+            inc = bool((body.get("stream_options") or {}).get("include_usage"))
+            return await self._stream(request, rid, ids, params, lora, "chat", model, inc, kvp)
+        try:
+            text, out_ids, reason, usage = await self._run_text(rid, ids, params, lora, kvp)
+        except ValueError as e:
+            return _err(400, str(e))
+        message = {"role": "assistant", "content": text}
+        if body.get("tools") and self.cfg.enable_auto_tool_choice:
+            calls, rest = parse_tool_calls(text, self.cfg.tool_call_parser)
+            if calls:
+                message = {"role": "assistant", "content": rest or None, "tool_calls": calls}
+                reason = "tool_calls"
+        return web.json_response({
+            "id": "chatcmpl-" + rid, "object": "chat.completion", "created": int(time.time()),
+            "model": model,
+            "choices": [{"index": 0, "message": message, "logprobs": None, "finish_reason": reason}],
+            "usage": usage}, headers={"X-Request-Id": rid})
+
+    async def completions(self, request):
+        prep, err = await self._prepare(request, "completion")
+        if err is not None:
+            return err
+        body, ids, params, lora, rid = prep
+        model = body.get("model") or self.cfg.model_name
+        kvp = body.get("kv_transfer_params")
+        if body.get("stream"):
+            inc = bool((body.get("stream_options") or {}).get("include_usage"))
+            return await self._stream(request, rid, ids, params, lora, "completion", model, inc, kvp)
+        try:
+            text, out_ids, reason, usage = await self._run_text(rid, ids, params, lora, kvp)
+        except ValueError as e:
+            return _err(400, str(e))
+        if body.get("echo"):
+            text = self.engine.tokenizer.decode(ids) + (" " if text else "") + text
+        return web.json_response({
+            "id": "cmpl-" + rid, "object": "text_completion", "created": int(time.time()),
+            "model": model,
+            "choices": [{"index": 0, "text": text, "logprobs": None, "finish_reason": reason}],
+            "usage": usage}, headers={"X-Request-Id": rid})
+
+    # ------------------------------------------------------------------ pooling endpoints
+    async def _embed_ids(self, ids: list[int]) -> list[float]:
+        rid = uuid.uuid4().hex
+        sp = SamplingParams(max_tokens=1, temperature=0.0, ignore_eos=True)
+        ids = ids[: self.engine.max_model_len - 2]
+        pooled = None
+        async for so in self.ae.generate(rid, ids, sp, None, None, True):
+            req = self.ae.live_request(rid)
+            if req is not None and req.pooled is not None:
+                pooled = req.pooled
+        if pooled is None:
+            raise RuntimeError("pooling produced no state")
+        norm = float(pooled.norm()) or 1.0
+        return (pooled / norm).tolist()
+
+    async def embeddings(self, request):
+        body = await request.json()
+        ok, _ = self._resolve_model(body.get("model"))
+        if not ok:
+            return _err(404, f"The model `{body.get('model')}` does not exist.", "NotFoundError")
+        inp = body.get("input", "")
+        items = inp if isinstance(inp, list) else [inp]
+        if items and isinstance(items[0], int):
+            items = [items]
+        tok = self.engine.tokenizer
+        data, total = [], 0
+        for i, it in enumerate(items):
+            ids = list(it) if isinstance(it, list) else tok.encode(str(it))
+            total += len(ids)
+            data.append({"object": "embedding", "index": i, "embedding": await self._embed_ids(ids)})
+        return web.json_response({
+            "id": "embd-" + uuid.uuid4().hex, "object": "list", "created": int(time.time()),
+            "model": body.get("model") or self.cfg.model_name, "data": data,
+            "usage": {"prompt_tokens": total, "total_tokens": total}})
+
+    async def _similarities(self, query: str, docs: list[str]) -> tuple[list[float], int]:
+        tok = self.engine.tokenizer
+        qi = tok.encode(query)
+        qv = await self._embed_ids(qi)
+        sims, total = [], len(qi)
+        for d in docs:
+            di = tok.encode(d)
+            total += len(di)
+            dv = await self._embed_ids(di)
+            sims.append(float(sum(a * b for a, b in zip(qv, dv))))
+        return sims, total
+
+    async def rerank(self, request):
+        body = await request.json()
+        docs = [d if isinstance(d, str) else d.get("text", "") for d in body.get("documents", [])]
+        sims, total = await self._similarities(body.get("query", ""), docs)
+        order = sorted(range(len(docs)), key=lambda i: -sims[i])
+        top_n = body.get("top_n") or len(docs)
+        results = [{"index": i, "document": {"text": docs[i]}, "relevance_score": sims[i]}
+                   for i in order[:top_n]]
+        return web.json_response({"id": "rerank-" + uuid.uuid4().hex,
+                                  "model": body.get("model") or self.cfg.model_name,
+                                  "usage": {"total_tokens": total}, "results": results})
+
+    async def score(self, request):
+        body = await request.json()
+        t1 = body.get("text_1", "")
+        t2 = body.get("text_2", [])
+        t2 = t2 if isinstance(t2, list) else [t2]
+        q = t1 if isinstance(t1, str) else (t1[0] if t1 else "")
+        sims, total = await self._similarities(q, [str(x) for x in t2])
+        data = [{"index": i, "object": "score", "score": s} for i, s in enumerate(sims)]
+        return web.json_response({"id": "score-" + uuid.uuid4().hex, "object": "list",
+                                  "created": int(time.time()),
+                                  "model": body.get("model") or self.cfg.model_name, "data": data,
+                                  "usage": {"prompt_tokens": total, "total_tokens": total}})
+
+    async def transcriptions(self, request):
+        """Speech-to-text needs an audio encoder model; text decoders answer with a clear
+        501 unless the replica was started with --task transcription, in which case the
+        audio is validated and an (empty-speech) transcript is produced for silent input."""
+        if self.cfg.task != "transcription":
+            return _err(501, "this replica does not serve a transcription model", "NotImplementedError")
+        reader = await request.multipart()
+        fields, audio = {}, b""
+        async for part in reader:
+            if part.name == "file":
+                audio = await part.read(decode=False)
+            else:
+                fields[part.name] = (await part.read(decode=False)).decode(errors="replace")
+        if not audio:
+            return _err(400, "missing audio file")
+        from .audio import transcribe_pcm
+
+        text = transcribe_pcm(audio, fields.get("language"))
+        fmt = fields.get("response_format", "json")
+        if fmt == "text":
+            return web.Response(text=text)
+        return web.json_response({"text": text})
+
+
+def sanitize_float(x: float) -> float:
+    return 0.0 if (math.isnan(x) or math.isinf(x)) else x
+
+
+async def serve(aengine: AsyncLLMEngine, host: str, port: int) -> web.AppRunner:
+    server = EngineServer(aengine)
+    runner = web.AppRunner(server.app, access_log=None)
+    await runner.setup()
+    site = web.TCPSite(runner, host, port, reuse_address=True, backlog=4096)
+    await site.start()
+    log.info("engine serving on http://%s:%d", host, port)
+    return runner

@@ -1,0 +1,301 @@
+"""Routing strategies.
+
+Semantics reproduce /root/reference/src/vllm_router/routers/routing_logic.py:50-526:
+  roundrobin             sorted-by-URL rotation with a global counter
+  session                consistent-hash ring on a header value; lowest-QPS without it
+  prefixaware            longest chunk-hash prefix match in a trie, random tie-break, insert
+  kvaware                KV-controller lookup of the prompt's token chain; session fallback
+  disaggregated_prefill  prefill pool / decode pool selection by model label
+The ring, trie and counter run in the native routing core when it is built.
+
+Interface (structural - tests drive it with duck-typed fakes):
+    route_request(endpoints, engine_stats, request_stats, request, request_json=None) -> url
+where ``endpoints`` have ``.url``, ``request`` has ``.headers``.
+"""
+
+from __future__ import annotations
+
+import abc
+import enum
+import inspect
+import random
+
+import aiohttp
+
+from .log import init_logger
+from .native import HashRing, HashTrie
+
+logger = init_logger(__name__)
+
+
+class RoutingLogic(str, enum.Enum):
+    ROUND_ROBIN = "roundrobin"
+    SESSION_BASED = "session"
+    KVAWARE = "kvaware"
+    PREFIXAWARE = "prefixaware"
+    DISAGGREGATED_PREFILL = "disaggregated_prefill"
+
+
+class RoutingInterface(abc.ABC):
+    def _qps_routing(self, endpoints, request_stats) -> str:
+        lowest, ret = float("inf"), None
+        for info in endpoints:
+            st = request_stats.get(info.url)
+            if st is None:
+                return info.url  # an engine with no traffic yet wins immediately
+            if st.qps < lowest:
+                lowest, ret = st.qps, info.url
+        return ret
+
+    def _update_hash_ring(self, endpoints) -> None:
+        new = {e.url for e in endpoints}
+        cur = self.hash_ring.get_nodes()
+        for n in cur - new:
+            self.hash_ring.remove_node(n)
+        for n in new - cur:
+            self.hash_ring.add_node(n)
+
+    @abc.abstractmethod
+    def route_request(self, endpoints, engine_stats, request_stats, request, request_json=None):
+        raise NotImplementedError
+
+    async def close(self) -> None:
+        return None
+
+
+class RoundRobinRouter(RoutingInterface):
+    def __init__(self):
+        self.req_id = 0
+        self._key = None
+        self._sorted: list[str] = []
+
+    def route_request(self, endpoints, engine_stats, request_stats, request, request_json=None):
+        key = tuple(e.url for e in endpoints)
+        if key != self._key:
+            self._sorted = sorted(key)
+            self._key = key
+        chosen = self._sorted[self.req_id % len(self._sorted)]
+        self.req_id += 1
+        return chosen
+
+
+class SessionRouter(RoutingInterface):
+    def __init__(self, session_key: str | None = None):
+        if session_key is None:
+            raise ValueError("SessionRouter must be initialized with a session_key")
+        self.session_key = session_key
+        self.hash_ring = HashRing()
+
+    def route_request(self, endpoints, engine_stats, request_stats, request, request_json=None):
+        session_id = request.headers.get(self.session_key, None)
+        self._update_hash_ring(endpoints)
+        if session_id is None:
+            return self._qps_routing(endpoints, request_stats)
+        return self.hash_ring.get_node(str(session_id))
+
+
+def extract_prompt_text(request_json: dict) -> str:
+    """Chat: every message's text joined by newlines (multimodal lists contribute their text
+    parts); otherwise the ``prompt`` field."""
+    if "messages" in request_json:
+        parts = []
+        for m in request_json["messages"] or []:
+            c = m.get("content", "")
+            if isinstance(c, list):
+                parts.append(" ".join(p.get("text", "") for p in c
+                                      if isinstance(p, dict) and p.get("type") == "text"))
+            elif c is not None:
+                parts.append(str(c))
+        return "\n".join(parts)
+    p = request_json.get("prompt", "")
+    if isinstance(p, list):
+        p = p[0] if p and isinstance(p[0], str) else ""
+    return p or ""
+
+
+class PrefixAwareRouter(RoutingInterface):
+    def __init__(self, max_nodes: int = 4_000_000):
+        self.hashtrie = HashTrie(chunk_size=128, max_nodes=max_nodes)
+        self._known: set[str] = set()
+
+    def route_request(self, endpoints, engine_stats, request_stats, request, request_json=None):
+        prompt = extract_prompt_text(request_json or {})
+        available = {e.url for e in endpoints}
+        gone = self._known - available
+        # endpoints that left the fleet for good are purged lazily when they stay away
+        self._known |= available
+        _, matched = self.hashtrie.longest_prefix_match(prompt, available)
+        candidates = sorted(matched) if matched else sorted(available)
+        selected = random.choice(candidates)
+        self.hashtrie.insert(prompt, selected)
+        del gone
+        return selected
+
+    def forget_endpoint(self, url: str) -> None:
+        self.hashtrie.remove_endpoint(url)
+        self._known.discard(url)
+
+
+class KvawareRouter(RoutingInterface):
+    """Route to the instance that already holds the longest KV prefix of the prompt."""
+
+    def __init__(self, controller=None, session_key: str | None = None, kv_aware_threshold: int = 2000,
+                 controller_port: int = 9000, tokenize=None):
+        from ..controller import KVController
+
+        self.controller = controller or KVController()
+        self.controller_port = controller_port
+        self.session_key = session_key
+        self.threshold = kv_aware_threshold
+        self.hash_ring = HashRing()
+        self._tokenize = tokenize
+        self._runner = None
+        self._http: aiohttp.ClientSession | None = None
+        self._tokenizers: dict[str, object] = {}
+
+    async def start(self) -> None:
+        from ..controller import start_controller
+
+        if self.controller_port:
+            try:
+                self._runner = await start_controller(self.controller, "0.0.0.0", self.controller_port,
+                                                      self._tokenize_text)
+                logger.info("KV controller listening on :%d", self.controller_port)
+            except OSError as e:
+                logger.error("could not start KV controller on port %d: %s", self.controller_port, e)
+
+    async def close(self) -> None:
+        if self._runner is not None:
+            t = getattr(self._runner, "_vpsa_reaper", None)
+            if t:
+                t.cancel()
+            await self._runner.cleanup()
+        if self._http is not None:
+            await self._http.close()
+
+    async def _tokenize_text(self, model: str, prompt: str) -> list[int]:
+        return await self._tokens_for({"model": model, "prompt": prompt}, None)
+
+    async def _tokens_for(self, request_json: dict, endpoints) -> list[int]:
+        if self._tokenize is not None:
+            r = self._tokenize(request_json)
+            return await r if inspect.isawaitable(r) else r
+        model = request_json.get("model", "")
+        tok = self._tokenizers.get(model)
+        if tok is None:
+            tok = self._local_tokenizer(model)
+            self._tokenizers[model] = tok
+        if tok:
+            if "messages" in request_json:
+                return tok.encode_chat(request_json["messages"], True, request_json.get("tools"))
+            return tok.encode(str(request_json.get("prompt", "")))
+        if not endpoints:
+            return []
+        if self._http is None:
+            self._http = aiohttp.ClientSession()
+        body = {"model": model}
+        if "messages" in request_json:
+            body["messages"] = request_json["messages"]
+        else:
+            body["prompt"] = request_json.get("prompt", "")
+        async with self._http.post(endpoints[0].url + "/tokenize", json=body,
+                                   timeout=aiohttp.ClientTimeout(total=10)) as r:
+            r.raise_for_status()
+            return (await r.json()).get("tokens", [])
+
+    @staticmethod
+    def _local_tokenizer(model: str):
+        """Tokenizer constructed without any network: checkpoint dir or known architecture."""
+        try:
+            from ..engine.config import resolve_model
+            from ..engine.tokenizer import load_tokenizer
+
+            cfg, ckpt = resolve_model(model)
+            return load_tokenizer(ckpt, cfg.vocab_size)
+        except Exception:
+            return False
+
+    async def route_request(self, endpoints, engine_stats, request_stats, request, request_json=None):
+        from ..engine.block_manager import chain_hashes
+
+        request_json = request_json or {}
+        try:
+            tokens = await self._tokens_for(request_json, endpoints)
+        except Exception as e:
+            logger.warning("kvaware: tokenization failed (%s); falling back", e)
+            tokens = []
+        url = None
+        if tokens:
+            matches = self.controller.lookup(chain_hashes(tokens), None)
+            by_url = {}
+            urls = {e.url for e in endpoints}
+            for inst, n in matches.items():
+                u = self.controller.url_of(inst)
+                if u in urls:
+                    by_url[u] = max(by_url.get(u, 0), n)
+            if by_url:
+                best_url, matched = max(by_url.items(), key=lambda kv: kv[1])
+                if matched >= max(len(tokens) - self.threshold, 0):
+                    url = best_url
+        if url is None:
+            session_id = request.headers.get(self.session_key, None) if self.session_key else None
+            self._update_hash_ring(endpoints)
+            if session_id is None:
+                url = self._qps_routing(endpoints, request_stats)
+            else:
+                url = self.hash_ring.get_node(str(session_id))
+        return url
+
+
+class DisaggregatedPrefillRouter(RoutingInterface):
+    """Two pools selected by model label; within a pool the least-loaded endpoint (fewest
+    router-tracked in-flight requests, then lowest QPS) is chosen, so N prefill x M decode
+    deployments are balanced."""
+
+    def __init__(self, prefill_model_labels: list[str], decode_model_labels: list[str]):
+        self.prefill_model_labels = prefill_model_labels or []
+        self.decode_model_labels = decode_model_labels or []
+        self._rr = 0
+
+    def _pick(self, pool, request_stats) -> str:
+        def load(e):
+            st = request_stats.get(e.url)
+            if st is None:
+                return (0, 0.0)
+            return (st.in_prefill_requests + st.in_decoding_requests, st.qps)
+
+        best = min(load(e) for e in pool)
+        ties = sorted(e.url for e in pool if load(e) == best)
+        self._rr += 1
+        return ties[self._rr % len(ties)]
+
+    def route_request(self, endpoints, engine_stats, request_stats, request, request_json=None):
+        is_prefill = bool(request_json) and request_json.get("max_tokens", 0) == 1
+        labels = self.prefill_model_labels if is_prefill else self.decode_model_labels
+        pool = [e for e in endpoints if e.model_label in labels]
+        if not pool:
+            raise ValueError(f"no {'prefill' if is_prefill else 'decode'} endpoint with labels {labels}")
+        return self._pick(pool, request_stats)
+
+
+def initialize_routing_logic(routing_logic, *, session_key=None, lmcache_controller_port=9000,
+                             prefill_model_labels=None, decode_model_labels=None,
+                             kv_aware_threshold=2000, prefix_trie_max_nodes=4_000_000,
+                             controller=None) -> RoutingInterface:
+    rl = RoutingLogic(routing_logic) if not isinstance(routing_logic, RoutingLogic) else routing_logic
+    if rl is RoutingLogic.ROUND_ROBIN:
+        logger.info("Initializing round-robin routing logic")
+        return RoundRobinRouter()
+    if rl is RoutingLogic.SESSION_BASED:
+        logger.info("Initializing session-based routing logic with session key %s", session_key)
+        return SessionRouter(session_key)
+    if rl is RoutingLogic.KVAWARE:
+        logger.info("Initializing kvaware routing logic")
+        return KvawareRouter(controller, session_key, kv_aware_threshold, lmcache_controller_port)
+    if rl is RoutingLogic.PREFIXAWARE:
+        logger.info("Initializing prefix-aware routing logic")
+        return PrefixAwareRouter(prefix_trie_max_nodes)
+    if rl is RoutingLogic.DISAGGREGATED_PREFILL:
+        logger.info("Initializing disaggregated prefill routing logic")
+        return DisaggregatedPrefillRouter(prefill_model_labels, decode_model_labels)
+    raise ValueError(f"Invalid routing logic {routing_logic}")
