@@ -44,7 +44,7 @@ class FakeKubeAPI:
         return web.json_response({})
 
     async def start(self):
-        self.runner = web.AppRunner(self.app, access_log=None)
+        self.runner = web.AppRunner(self.app, access_log=None, shutdown_timeout=0.2)
         await self.runner.setup()
         site = web.TCPSite(self.runner, "127.0.0.1", 0)
         await site.start()

@@ -114,26 +114,39 @@ def extract_prompt_text(request_json: dict) -> str:
 
 
 class PrefixAwareRouter(RoutingInterface):
-    def __init__(self, max_nodes: int = 4_000_000):
+    """Longest-prefix affinity with load-aware tie-breaking.
+
+    A match is honoured when it covers at least ``min_match_ratio`` of the prompt (a mere
+    shared system prompt must not pin every conversation to one engine); among the
+    candidate endpoints the one with the fewest router-tracked in-flight requests wins, with
+    a random choice between equals.  ``min_match_ratio=0`` and no request statistics give
+    the reference behaviour: any match wins, random choice among the matched endpoints."""
+
+    def __init__(self, max_nodes: int = 4_000_000, min_match_ratio: float = 0.5):
         self.hashtrie = HashTrie(chunk_size=128, max_nodes=max_nodes)
-        self._known: set[str] = set()
+        self.min_match_ratio = min_match_ratio
+
+    @staticmethod
+    def _least_loaded(urls: list[str], request_stats) -> str:
+        def load(u):
+            st = request_stats.get(u) if request_stats else None
+            return 0 if st is None else st.in_prefill_requests + st.in_decoding_requests
+
+        best = min(load(u) for u in urls)
+        return random.choice([u for u in urls if load(u) == best])
 
     def route_request(self, endpoints, engine_stats, request_stats, request, request_json=None):
         prompt = extract_prompt_text(request_json or {})
         available = {e.url for e in endpoints}
-        gone = self._known - available
-        # endpoints that left the fleet for good are purged lazily when they stay away
-        self._known |= available
-        _, matched = self.hashtrie.longest_prefix_match(prompt, available)
-        candidates = sorted(matched) if matched else sorted(available)
-        selected = random.choice(candidates)
+        matched_len, matched = self.hashtrie.longest_prefix_match(prompt, available)
+        strong = matched and matched_len >= self.min_match_ratio * len(prompt)
+        candidates = sorted(matched) if strong else sorted(available)
+        selected = self._least_loaded(candidates, request_stats)
         self.hashtrie.insert(prompt, selected)
-        del gone
         return selected
 
     def forget_endpoint(self, url: str) -> None:
         self.hashtrie.remove_endpoint(url)
-        self._known.discard(url)
 
 
 class KvawareRouter(RoutingInterface):
