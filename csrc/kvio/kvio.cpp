@@ -1,0 +1,278 @@
+// KV I/O engine for one GPU: pinned host-DRAM page pool, side-stream copy engine
+// (HBM <-> pinned host via hipMemcpyAsync, overlapped with compute), and the host half of
+// the CacheGen-style codec (adaptive binary-decomposed range coder over the quantised
+// symbols produced by the cachegen_encode kernel).
+//
+// Contract it fulfils (reference launches LMCache for this and only configures it):
+// LMCACHE_LOCAL_CPU / LMCACHE_MAX_LOCAL_CPU_SIZE host offload
+// (/root/reference/helm/templates/deployment-vllm-multi.yaml:306-313) and the remote
+// serde selection naive|cachegen (:321-322).
+//
+// Design for MI355X: a KV page (all layers of 64 tokens) is one contiguous run in HBM
+// (8 MiB for Llama-3-8B), so a page moves with a single large DMA.  The pool is one
+// hipHostMalloc'ed slab carved into page-sized slots (no per-transfer registration); copies
+// are issued on a dedicated non-blocking stream and fenced with events, never with a
+// device-wide synchronise.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <atomic>
+#include <mutex>
+#include <vector>
+
+#define API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+struct Pool {
+  char* base = nullptr;
+  size_t slot_bytes = 0;
+  size_t n_slots = 0;
+  std::vector<int64_t> free_list;
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  int device = 0;
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------- pinned pool
+API void* kvio_pool_create(int device, size_t slot_bytes, size_t n_slots) {
+  if (slot_bytes == 0 || n_slots == 0) return nullptr;
+  Pool* p = new Pool();
+  p->device = device;
+  p->slot_bytes = slot_bytes;
+  p->n_slots = n_slots;
+  if (hipSetDevice(device) != hipSuccess) {
+    delete p;
+    return nullptr;
+  }
+  if (hipHostMalloc((void**)&p->base, slot_bytes * n_slots, hipHostMallocDefault) != hipSuccess) {
+    delete p;
+    return nullptr;
+  }
+  if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) {
+    hipHostFree(p->base);
+    delete p;
+    return nullptr;
+  }
+  p->free_list.reserve(n_slots);
+  for (int64_t i = (int64_t)n_slots - 1; i >= 0; --i) p->free_list.push_back(i);
+  return p;
+}
+
+API void kvio_pool_destroy(void* h) {
+  Pool* p = static_cast<Pool*>(h);
+  if (!p) return;
+  hipStreamSynchronize(p->stream);
+  hipStreamDestroy(p->stream);
+  hipHostFree(p->base);
+  delete p;
+}
+
+API int64_t kvio_pool_alloc(void* h) {
+  Pool* p = static_cast<Pool*>(h);
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (p->free_list.empty()) return -1;
+  int64_t s = p->free_list.back();
+  p->free_list.pop_back();
+  return s;
+}
+
+API void kvio_pool_free(void* h, int64_t slot) {
+  Pool* p = static_cast<Pool*>(h);
+  std::lock_guard<std::mutex> lk(p->mu);
+  p->free_list.push_back(slot);
+}
+
+API size_t kvio_pool_free_slots(void* h) {
+  Pool* p = static_cast<Pool*>(h);
+  std::lock_guard<std::mutex> lk(p->mu);
+  return p->free_list.size();
+}
+
+API void* kvio_pool_slot_ptr(void* h, int64_t slot) {
+  Pool* p = static_cast<Pool*>(h);
+  if (slot < 0 || (size_t)slot >= p->n_slots) return nullptr;
+  return p->base + (size_t)slot * p->slot_bytes;
+}
+
+API void* kvio_pool_stream(void* h) { return static_cast<Pool*>(h)->stream; }
+
+// ---------------------------------------------------------------- copy engine
+// All copies run on the pool's side stream.  `wait_event` (may be null) is an event recorded
+// on the compute stream after the producing kernels; the returned event (created here, owned
+// by the caller -> kvio_event_destroy) fires when the batch of copies has landed.
+API void* kvio_event_create() {
+  hipEvent_t e;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+  return e;
+}
+API void kvio_event_destroy(void* e) {
+  if (e) hipEventDestroy((hipEvent_t)e);
+}
+API int kvio_event_record(void* e, void* stream) {
+  return (int)hipEventRecord((hipEvent_t)e, (hipStream_t)stream);
+}
+API int kvio_event_query(void* e) { return hipEventQuery((hipEvent_t)e) == hipSuccess ? 1 : 0; }
+API int kvio_event_sync(void* e) { return (int)hipEventSynchronize((hipEvent_t)e); }
+API int kvio_stream_wait_event(void* stream, void* e) {
+  return (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)e, 0);
+}
+
+// device pages -> pinned slots.  dev_base + page_ids[i] * page_bytes is the source.
+API int kvio_offload_pages(void* h, const void* dev_base, size_t page_bytes, const int64_t* page_ids,
+                           const int64_t* slots, int n, void* wait_event, void* done_event) {
+  Pool* p = static_cast<Pool*>(h);
+  if (page_bytes > p->slot_bytes) return -1;
+  if (wait_event && hipStreamWaitEvent(p->stream, (hipEvent_t)wait_event, 0) != hipSuccess) return -2;
+  for (int i = 0; i < n; ++i) {
+    const char* src = (const char*)dev_base + (size_t)page_ids[i] * page_bytes;
+    char* dst = p->base + (size_t)slots[i] * p->slot_bytes;
+    if (hipMemcpyAsync(dst, src, page_bytes, hipMemcpyDeviceToHost, p->stream) != hipSuccess) return -3;
+  }
+  if (done_event && hipEventRecord((hipEvent_t)done_event, p->stream) != hipSuccess) return -4;
+  return 0;
+}
+
+// pinned slots -> device pages.
+API int kvio_load_pages(void* h, void* dev_base, size_t page_bytes, const int64_t* page_ids,
+                        const int64_t* slots, int n, void* wait_event, void* done_event) {
+  Pool* p = static_cast<Pool*>(h);
+  if (page_bytes > p->slot_bytes) return -1;
+  if (wait_event && hipStreamWaitEvent(p->stream, (hipEvent_t)wait_event, 0) != hipSuccess) return -2;
+  for (int i = 0; i < n; ++i) {
+    char* dst = (char*)dev_base + (size_t)page_ids[i] * page_bytes;
+    const char* src = p->base + (size_t)slots[i] * p->slot_bytes;
+    if (hipMemcpyAsync(dst, src, page_bytes, hipMemcpyHostToDevice, p->stream) != hipSuccess) return -3;
+  }
+  if (done_event && hipEventRecord((hipEvent_t)done_event, p->stream) != hipSuccess) return -4;
+  return 0;
+}
+
+// ---------------------------------------------------------------- entropy coder (host)
+// Adaptive binary range coder (LZMA-style rc) over int8 symbols decomposed with a
+// per-context binary tree: 8 binary decisions per symbol, context = tree node.  Narrow
+// alphabets (late layers quantised to few levels) cost proportionally fewer bits.
+namespace {
+
+struct RcEnc {
+  uint64_t low = 0;
+  uint32_t range = 0xFFFFFFFFu;
+  uint8_t cache = 0;
+  uint64_t cache_size = 1;
+  uint8_t* out;
+  size_t cap, pos = 0;
+  bool overflow = false;
+  void put(uint8_t b) {
+    if (pos < cap)
+      out[pos++] = b;
+    else
+      overflow = true;
+  }
+  void shift_low() {
+    if ((uint32_t)low < 0xFF000000u || (int)(low >> 32) != 0) {
+      uint8_t temp = cache;
+      do {
+        put((uint8_t)(temp + (uint8_t)(low >> 32)));
+        temp = 0xFF;
+      } while (--cache_size != 0);
+      cache = (uint8_t)((uint32_t)low >> 24);
+    }
+    cache_size++;
+    low = (uint32_t)low << 8;
+  }
+  void encode(uint16_t* prob, int bit) {
+    uint32_t bound = (range >> 11) * *prob;
+    if (!bit) {
+      range = bound;
+      *prob += (2048 - *prob) >> 5;
+    } else {
+      low += bound;
+      range -= bound;
+      *prob -= *prob >> 5;
+    }
+    while (range < (1u << 24)) {
+      range <<= 8;
+      shift_low();
+    }
+  }
+  void flush() {
+    for (int i = 0; i < 5; ++i) shift_low();
+  }
+};
+
+struct RcDec {
+  uint32_t range = 0xFFFFFFFFu, code = 0;
+  const uint8_t* in;
+  size_t len, pos = 0;
+  uint8_t get() { return pos < len ? in[pos++] : 0; }
+  void init() {
+    get();
+    for (int i = 0; i < 4; ++i) code = (code << 8) | get();
+  }
+  int decode(uint16_t* prob) {
+    uint32_t bound = (range >> 11) * *prob;
+    int bit;
+    if (code < bound) {
+      range = bound;
+      *prob += (2048 - *prob) >> 5;
+      bit = 0;
+    } else {
+      code -= bound;
+      range -= bound;
+      *prob -= *prob >> 5;
+      bit = 1;
+    }
+    while (range < (1u << 24)) {
+      range <<= 8;
+      code = (code << 8) | get();
+    }
+    return bit;
+  }
+};
+
+}  // namespace
+
+// Returns bytes written, or -1 when `cap` is too small.  n_ctx independent model sets are
+// cycled every `ctx_period` symbols (e.g. one per layer) so each layer adapts separately.
+API int64_t kvio_rc_encode(const int8_t* sym, size_t n, uint8_t* out, size_t cap, size_t ctx_period,
+                           int n_ctx) {
+  if (n_ctx < 1) n_ctx = 1;
+  if (ctx_period == 0) ctx_period = n ? n : 1;
+  std::vector<uint16_t> probs((size_t)n_ctx * 256, 1024);
+  RcEnc e;
+  e.out = out;
+  e.cap = cap;
+  for (size_t i = 0; i < n; ++i) {
+    uint16_t* pr = probs.data() + ((i / ctx_period) % n_ctx) * 256;
+    unsigned v = (uint8_t)sym[i] ^ 0x80u;  // order symbols by value: -128..127 -> 0..255
+    unsigned node = 1;
+    for (int b = 7; b >= 0; --b) {
+      int bit = (v >> b) & 1;
+      e.encode(pr + node, bit);
+      node = (node << 1) | bit;
+    }
+  }
+  e.flush();
+  return e.overflow ? -1 : (int64_t)e.pos;
+}
+
+API int kvio_rc_decode(const uint8_t* in, size_t len, int8_t* sym, size_t n, size_t ctx_period,
+                       int n_ctx) {
+  if (n_ctx < 1) n_ctx = 1;
+  if (ctx_period == 0) ctx_period = n ? n : 1;
+  std::vector<uint16_t> probs((size_t)n_ctx * 256, 1024);
+  RcDec d;
+  d.in = in;
+  d.len = len;
+  d.init();
+  for (size_t i = 0; i < n; ++i) {
+    uint16_t* pr = probs.data() + ((i / ctx_period) % n_ctx) * 256;
+    unsigned node = 1;
+    for (int b = 0; b < 8; ++b) node = (node << 1) | (unsigned)d.decode(pr + node);
+    sym[i] = (int8_t)((node & 0xFF) ^ 0x80u);
+  }
+  return 0;
+}

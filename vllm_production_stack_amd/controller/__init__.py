@@ -154,7 +154,20 @@ def make_app(ctrl: KVController, tokenize=None) -> web.Application:
     return app
 
 
-async def start_controller(ctrl: KVController, host: str, port: int, tokenize=None) -> web.AppRunner:
+class ControllerHandle:
+    def __init__(self, runner: web.AppRunner, reaper: asyncio.Task):
+        self.runner, self.reaper = runner, reaper
+
+    @property
+    def addresses(self):
+        return self.runner.addresses
+
+    async def cleanup(self) -> None:
+        self.reaper.cancel()
+        await self.runner.cleanup()
+
+
+async def start_controller(ctrl: KVController, host: str, port: int, tokenize=None) -> ControllerHandle:
     runner = web.AppRunner(make_app(ctrl, tokenize), access_log=None)
     await runner.setup()
     await web.TCPSite(runner, host, port, reuse_address=True).start()
@@ -164,5 +177,4 @@ async def start_controller(ctrl: KVController, host: str, port: int, tokenize=No
             await asyncio.sleep(30)
             ctrl.reap_stale()
 
-    runner._vpsa_reaper = asyncio.create_task(reaper())
-    return runner
+    return ControllerHandle(runner, asyncio.create_task(reaper()))

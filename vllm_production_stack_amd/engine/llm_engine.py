@@ -9,6 +9,8 @@ directly.
 from __future__ import annotations
 
 import logging
+import os
+import sys
 import time
 import uuid
 
@@ -23,6 +25,7 @@ from .scheduler import Scheduler
 from .tokenizer import load_tokenizer
 
 log = logging.getLogger("vpsa.engine")
+_TRACE = bool(os.environ.get("VPSA_TRACE_STEPS"))
 
 
 class LLMEngine:
@@ -95,6 +98,10 @@ class LLMEngine:
             self.metrics.update_scheduler(self.scheduler, self.bm)
             return []
         now = time.time()
+        if _TRACE:
+            print("STEP dec=%d pre=%s free=%d" % (
+                len(out.decodes), [(s.start, s.n, len(s.req.pages)) for s in out.prefills],
+                self.bm.num_free()), file=sys.stderr, flush=True)
         results = self.runner.execute(out)
         sampled = {id(s): (tok, info) for s, tok, info in results}
         outputs: list[StepOutput] = []
@@ -120,13 +127,14 @@ class LLMEngine:
             req.last_token = t
             reason = self._stop_reason(req, tok)
             if reason:
+                if self.connector is not None:
+                    # while the request still owns its pages (P->D push reads them)
+                    self.connector.on_request_finished(req)
                 self.scheduler.finish(req, reason)
                 self.requests.pop(req.request_id, None)
                 self.runner.sampler.forget(req.request_id)
                 self.metrics.e2e.observe(t - req.arrival)
                 self.metrics.success.inc()
-                if self.connector is not None:
-                    self.connector.on_request_finished(req)
             outputs.append(StepOutput(req.request_id, [tok], reason is not None, reason,
                                       req.prompt_len, len(req.output_ids), req.num_cached_tokens + req.num_external_tokens))
         if self.connector is not None and fresh_pages:

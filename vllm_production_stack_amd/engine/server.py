@@ -87,6 +87,10 @@ class EngineServer:
         r.add_post("/reset_prefix_cache", self.reset_prefix_cache)
         r.add_get("/kv/lookup", self.kv_lookup)
         r.add_post("/kv/lookup", self.kv_lookup)
+        r.add_post("/kv/reserve", self.kv_reserve)
+        r.add_post("/kv/push", self.kv_push)
+        r.add_post("/kv/commit", self.kv_commit)
+        self._receiver = None
 
     # ------------------------------------------------------------------ middleware
     @web.middleware
@@ -188,6 +192,37 @@ class EngineServer:
         if self.engine.connector is not None and n < len(hashes):
             n += self.engine.connector.lookup(hashes[n:])
         return web.json_response({"matched_tokens": n * PAGE, "total_tokens": len(tokens)})
+
+    # ------------------------------------------------------------------ P->D KV receive side
+    def _kv_receiver(self):
+        if self._receiver is None:
+            from ..parallel.kv_transfer import KVReceiver
+
+            self._receiver = KVReceiver(self.engine)
+        return self._receiver
+
+    async def kv_reserve(self, request):
+        d = await request.json()
+        rcv = self._kv_receiver()
+        try:
+            res = await self.ae.call(lambda: rcv.reserve(d["hashes"], int(d["page_bytes"])))
+        except (ValueError, MemoryError) as e:
+            return _err(409, str(e), "KVTransferError")
+        return web.json_response(res)
+
+    async def kv_push(self, request):
+        raw = await request.read()
+        n = int.from_bytes(raw[:4], "little")
+        meta = json.loads(raw[4:4 + n])
+        rcv = self._kv_receiver()
+        res = await self.ae.call(lambda: rcv.push(meta["pages"], raw[4 + n:]))
+        return web.json_response(res)
+
+    async def kv_commit(self, request):
+        d = await request.json()
+        rcv = self._kv_receiver()
+        res = await self.ae.call(lambda: rcv.commit(d["hashes"], d["pages"]))
+        return web.json_response(res)
 
     # ------------------------------------------------------------------ LoRA
     async def load_lora(self, request):

@@ -1,0 +1,185 @@
+"""Prefill -> decode KV page transfer between engine replicas (disaggregated prefill).
+
+Protocol (control plane = the replicas' own HTTP ports, data plane chosen per pair):
+  1. producer  POST <decode>/kv/reserve {hashes}      -> {pages, missing, transports...}
+     the decode replica allocates HBM pages for the hashes it does not hold yet;
+  2. producer  moves the page bytes:
+        ipc   the decode pool is mapped through a hipIpc handle and written with
+              hipMemcpyAsync on a side stream (SDMA over the direct xGMI link),
+        rccl  torch.distributed batched isend/irecv (RCCL send/recv) when both replicas
+              are ranks of one process group,
+        tcp   POST <decode>/kv/push with the raw page bytes (any host, CPU tests);
+  3. producer  POST <decode>/kv/commit {hashes, pages} -> pages are published in the decode
+     replica's prefix cache; the decode request then finds its prompt resident.
+Reference behaviour being provided: the NIXL sender/receiver pair configured by
+LMCACHE_NIXL_* (/root/reference/helm/templates/deployment-vllm-multi.yaml:267-305) and the
+router's two-phase request flow (/root/reference/src/vllm_router/services/request_service/request.py:339-431).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import json
+import logging
+import urllib.request
+from ctypes import c_int, c_size_t, c_void_p
+
+import torch
+
+from .. import _native
+
+log = logging.getLogger("vpsa.kvxfer")
+_comm = None
+_peer_maps: dict[str, tuple[int, int]] = {}  # target url -> (mapped base ptr, page_bytes)
+
+
+def comm():
+    global _comm
+    if _comm is None:
+        lib = _native.load("vpsa_comm")
+        lib.comm_ipc_handle_size.restype = c_int
+        lib.comm_ipc_export.restype = c_int
+        lib.comm_ipc_export.argtypes = [c_void_p, c_void_p]
+        lib.comm_ipc_open.restype = c_void_p
+        lib.comm_ipc_open.argtypes = [c_void_p]
+        lib.comm_ipc_close.argtypes = [c_void_p]
+        lib.comm_push_pages.restype = c_int
+        lib.comm_push_pages.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p]
+        _comm = lib
+    return _comm
+
+
+def _post(url: str, payload: dict, raw: bytes | None = None, timeout: float = 60.0) -> dict:
+    if raw is None:
+        data = json.dumps(payload).encode()
+        headers = {"Content-Type": "application/json"}
+    else:
+        meta = json.dumps(payload).encode()
+        data = len(meta).to_bytes(4, "little") + meta + raw
+        headers = {"Content-Type": "application/octet-stream"}
+    req = urllib.request.Request(url, data=data, headers=headers)
+    with urllib.request.urlopen(req, timeout=timeout) as r:
+        body = r.read()
+    return json.loads(body) if body else {}
+
+
+def export_ipc_handle(pool: torch.Tensor) -> str | None:
+    """Hex hipIpc handle of the KV pool allocation (decode side)."""
+    if not pool.is_cuda:
+        return None
+    try:
+        lib = comm()
+        n = lib.comm_ipc_handle_size()
+        buf = ctypes.create_string_buffer(n)
+        base = pool.untyped_storage().data_ptr()
+        if lib.comm_ipc_export(c_void_p(base), buf) != 0:
+            return None
+        return buf.raw.hex()
+    except Exception as e:
+        log.warning("hipIpc export failed: %s", e)
+        return None
+
+
+def push_request_pages(engine, target: str, hashes: list[int], pages: list[int]) -> str:
+    """Producer side: make ``hashes`` resident on the decode replica at ``target``."""
+    runner = engine.runner
+    pool = runner.pool
+    page_bytes = pool.stride(0) * pool.element_size()
+    res = _post(target + "/kv/reserve", {"hashes": hashes, "page_bytes": page_bytes,
+                                         "source_rank": _my_rank()})
+    dst_pages = res.get("pages", [])
+    missing = res.get("missing", [])
+    if not missing:
+        return "resident"
+    idx = {h: i for i, h in enumerate(hashes)}
+    src = [pages[idx[h]] for h in missing]
+    mode = "tcp"
+    if pool.is_cuda and res.get("ipc_handle") and res.get("same_host"):
+        try:
+            _push_ipc(pool, target, res["ipc_handle"], res.get("pool_offset", 0), page_bytes, src, dst_pages)
+            mode = "ipc"
+        except Exception as e:
+            log.warning("ipc push failed (%s); falling back to tcp", e)
+    if mode == "tcp":
+        chunk = 8
+        for i in range(0, len(src), chunk):
+            blob = pool[torch.tensor(src[i:i + chunk], device=pool.device)].contiguous().cpu()
+            raw = blob.view(torch.uint8).numpy().tobytes()
+            _post(target + "/kv/push", {"pages": dst_pages[i:i + chunk], "page_bytes": page_bytes}, raw)
+    _post(target + "/kv/commit", {"hashes": missing, "pages": dst_pages})
+    return mode
+
+
+def _my_rank() -> int:
+    import torch.distributed as dist
+
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else -1
+
+
+def _push_ipc(pool, target, handle_hex, pool_offset, page_bytes, src_pages, dst_pages) -> None:
+    lib = comm()
+    ent = _peer_maps.get(target)
+    if ent is None:
+        h = bytes.fromhex(handle_hex)
+        base = lib.comm_ipc_open(ctypes.create_string_buffer(h, len(h)))
+        if not base:
+            raise RuntimeError("hipIpcOpenMemHandle failed")
+        ent = (base, page_bytes)
+        _peer_maps[target] = ent
+    n = len(src_pages)
+    sp = (ctypes.c_int64 * n)(*src_pages)
+    dp = (ctypes.c_int64 * n)(*dst_pages)
+    stream = torch.cuda.Stream(device=pool.device)
+    stream.wait_stream(torch.cuda.current_stream())
+    rc = lib.comm_push_pages(c_void_p(pool.data_ptr()), c_void_p(ent[0] + pool_offset), page_bytes,
+                             sp, dp, n, c_void_p(stream.cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"comm_push_pages failed ({rc})")
+    stream.synchronize()
+
+
+# ------------------------------------------------------------------ decode side (engine thread)
+class KVReceiver:
+    """Runs inside the decode replica; methods are invoked on the engine thread."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.reserved: dict[int, int] = {}  # hash -> page reserved for an in-flight transfer
+        self._handle = None
+
+    def reserve(self, hashes: list[int], page_bytes: int) -> dict:
+        bm = self.engine.bm
+        pool = self.engine.runner.pool
+        mine = pool.stride(0) * pool.element_size()
+        if page_bytes != mine:
+            raise ValueError(f"page size mismatch: sender {page_bytes}, receiver {mine}")
+        missing = [h for h in hashes if not bm.contains(h) and h not in self.reserved]
+        if missing and not bm.can_allocate(len(missing)):
+            raise MemoryError("decode replica has no free KV pages for the transfer")
+        pages = bm.allocate(len(missing)) if missing else []
+        for h, p in zip(missing, pages):
+            self.reserved[h] = p
+        if self._handle is None:
+            self._handle = export_ipc_handle(pool) or ""
+        import socket
+
+        return {"pages": pages, "missing": missing, "ipc_handle": self._handle or None,
+                "pool_offset": pool.data_ptr() - pool.untyped_storage().data_ptr() if pool.is_cuda else 0,
+                "same_host": True, "host": socket.gethostname()}
+
+    def push(self, pages: list[int], raw: bytes) -> dict:
+        pool = self.engine.runner.pool
+        n = len(pages)
+        t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).view(pool.dtype).view(n, *pool.shape[1:])
+        pool[torch.tensor(pages, device=pool.device)] = t.to(pool.device)
+        return {"ok": True}
+
+    def commit(self, hashes: list[int], pages: list[int]) -> dict:
+        bm = self.engine.bm
+        if self.engine.runner.device.type == "cuda":
+            torch.cuda.synchronize()
+        for h, p in zip(hashes, pages):
+            self.reserved.pop(h, None)
+            bm.register(p, h)
+        bm.free(pages)  # published pages wait in the prefix cache (evictable, LRU)
+        return {"ok": True, "published": len(pages)}

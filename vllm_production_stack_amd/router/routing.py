@@ -179,9 +179,6 @@ class KvawareRouter(RoutingInterface):
 
     async def close(self) -> None:
         if self._runner is not None:
-            t = getattr(self._runner, "_vpsa_reaper", None)
-            if t:
-                t.cancel()
             await self._runner.cleanup()
         if self._http is not None:
             await self._http.close()
