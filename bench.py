@@ -251,6 +251,8 @@ async def rank_main(a: argparse.Namespace) -> None:
                            "routing": a.routing_logic,
                            "kv_pages_per_replica": engine.runner.num_pages,
                            "cpu_offload_gb": a.cpu_offload_gb},
+                "engine0_profile": {k: (round(v, 3) if isinstance(v, float) else v)
+                                    for k, v in engine.prof.items()},
             }
             print(json.dumps(result), flush=True)
         await runner.cleanup()

@@ -46,6 +46,9 @@ class LLMEngine:
             self.tokenizer.eos_token_id}
         self.lora_manager = None
         self.step_count = 0
+        # coarse step-loop profile (seconds), read by /debug/stats and the benchmark
+        self.prof = {"steps": 0, "decode_only_steps": 0, "mixed_steps": 0, "t_schedule": 0.0,
+                     "t_execute": 0.0, "t_post": 0.0, "rows": 0}
         self._init_kv_tiers()
         log.info("engine ready: %d KV pages (%d tokens, %.1f GiB), max_model_len=%d",
                  self.runner.num_pages, self.runner.num_pages * PAGE,
@@ -92,7 +95,9 @@ class LLMEngine:
 
     # ------------------------------------------------------------------ step
     def step(self) -> list[StepOutput]:
+        t_a = time.perf_counter()
         out = self.scheduler.schedule()
+        t_b = time.perf_counter()
         self.step_count += 1
         if out.empty:
             self.metrics.update_scheduler(self.scheduler, self.bm)
@@ -103,6 +108,7 @@ class LLMEngine:
                 len(out.decodes), [(s.start, s.n, len(s.req.pages)) for s in out.prefills],
                 self.bm.num_free()), file=sys.stderr, flush=True)
         results = self.runner.execute(out)
+        t_c = time.perf_counter()
         sampled = {id(s): (tok, info) for s, tok, info in results}
         outputs: list[StepOutput] = []
         fresh_pages: list[tuple[int, int]] = []
@@ -141,6 +147,13 @@ class LLMEngine:
             self.connector.store_pages(fresh_pages)
         self.metrics.update_scheduler(self.scheduler, self.bm)
         del now
+        pr = self.prof
+        pr["steps"] += 1
+        pr["decode_only_steps" if not out.prefills else "mixed_steps"] += 1
+        pr["rows"] += out.num_tokens
+        pr["t_schedule"] += t_b - t_a
+        pr["t_execute"] += t_c - t_b
+        pr["t_post"] += time.perf_counter() - t_c
         return outputs
 
     def _stop_reason(self, req: Request, tok: int) -> str | None:

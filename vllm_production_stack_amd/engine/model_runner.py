@@ -228,7 +228,8 @@ class ModelRunner:
             logits, toks = run()
         if self._graph_pool is None:
             self._graph_pool = g.pool()
-        st.update(graph=g, logits=logits, toks=toks)
+        # the graph's kernels hold raw pointers into the split-K workspaces: keep them alive
+        st.update(graph=g, logits=logits, toks=toks, meta=meta, ws_o=ws_o, ws_ml=ws_ml)
         return st
 
     def _execute_decode_graph(self, decodes: list[ScheduledSeq]):

@@ -87,6 +87,7 @@ class EngineServer:
         r.add_post("/reset_prefix_cache", self.reset_prefix_cache)
         r.add_get("/kv/lookup", self.kv_lookup)
         r.add_post("/kv/lookup", self.kv_lookup)
+        r.add_get("/debug/stats", self.debug_stats)
         r.add_post("/kv/reserve", self.kv_reserve)
         r.add_post("/kv/push", self.kv_push)
         r.add_post("/kv/commit", self.kv_commit)
@@ -192,6 +193,12 @@ class EngineServer:
         if self.engine.connector is not None and n < len(hashes):
             n += self.engine.connector.lookup(hashes[n:])
         return web.json_response({"matched_tokens": n * PAGE, "total_tokens": len(tokens)})
+
+    async def debug_stats(self, request):
+        e = self.engine
+        return web.json_response({"prof": e.prof, "preemptions": e.scheduler.num_preemptions,
+                                  "prefix_hits": e.bm.hits, "prefix_queries": e.bm.queries,
+                                  "free_pages": e.bm.num_free(), "graphs": sorted(e.runner._graphs)})
 
     # ------------------------------------------------------------------ P->D KV receive side
     def _kv_receiver(self):

@@ -88,6 +88,7 @@ class SyntheticTokenizer(BaseTokenizer):
         self._base = 16
         self._space = max(1, vocab_size - self._base)
         self._words: dict[int, str] = {}
+        self._memo: dict[str, int] = {}
 
     def _word_id(self, w: str) -> int:
         if w in self._special:
@@ -101,7 +102,23 @@ class SyntheticTokenizer(BaseTokenizer):
         return i
 
     def encode(self, text: str, add_special_tokens: bool = True) -> list[int]:
-        ids = [self._word_id(w) for w in self._WORD.findall(text)]
+        # str.split + a memo table handles the common case at C speed; the regex is only needed
+        # when a special token is glued to other characters
+        words = text.split()
+        memo = self._memo
+        try:
+            ids = [memo[w] for w in words]
+        except KeyError:
+            ids = []
+            for w in words:
+                i = memo.get(w)
+                if i is None:
+                    if "<|" in w and w not in self._special:
+                        sub = [self._word_id(x) for x in self._WORD.findall(w)]
+                        ids.extend(sub)
+                        continue
+                    i = memo[w] = self._word_id(w)
+                ids.append(i)
         if add_special_tokens and (not ids or ids[0] != self.bos_token_id):
             ids.insert(0, self.bos_token_id)
         return ids
