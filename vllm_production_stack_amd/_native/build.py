@@ -47,7 +47,7 @@ def _stale(out: Path, srcs: list[Path]) -> bool:
     if not out.exists():
         return True
     t = out.stat().st_mtime
-    deps = list(srcs)
+    deps = list(srcs) + list((CSRC / "common").glob("*.hpp"))
     for s in srcs:
         deps.extend(s.parent.glob("*.h"))
         deps.extend(s.parent.glob("*.hpp"))
