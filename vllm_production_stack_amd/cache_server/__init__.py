@@ -119,7 +119,10 @@ def main(argv: list[str] | None = None) -> None:
     ap.add_argument("host", nargs="?", default="0.0.0.0")
     ap.add_argument("port", nargs="?", type=int, default=8000)
     ap.add_argument("--max-size-gb", type=float, default=64.0)
+    ap.add_argument("--max-bytes", type=int, default=None, help="capacity in bytes (overrides --max-size-gb)")
     a = ap.parse_args(argv)
+    if a.max_bytes:
+        a.max_size_gb = a.max_bytes / (1 << 30)
 
     async def run():
         srv = await CacheServer(a.host, a.port, int(a.max_size_gb * (1 << 30))).start()

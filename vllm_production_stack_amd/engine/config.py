@@ -283,7 +283,10 @@ class EngineConfig:
             if torch.cuda.is_available():
                 return torch.device("cuda", torch.cuda.current_device())
             return torch.device("cpu")
-        return torch.device(self.device)
+        dev = torch.device(self.device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        return dev
 
     @property
     def model_name(self) -> str:

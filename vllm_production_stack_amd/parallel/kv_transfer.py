@@ -183,3 +183,44 @@ class KVReceiver:
             bm.register(p, h)
         bm.free(pages)  # published pages wait in the prefix cache (evictable, LRU)
         return {"ok": True, "published": len(pages)}
+
+
+def local_push(src_engine, receiver: "KVReceiver", prompt_ids: list[int]) -> int:
+    """Same-process P->D transfer (two engines sharing a device or both on the CPU): the
+    reserve/push/commit protocol with the HTTP hops removed.  On a GPU the bytes move with the
+    same side-stream page copier the hipIpc data plane uses, so this exercises
+    ``comm_push_pages`` without a second process.  Returns the number of pages moved."""
+    from ..engine.block_manager import chain_hashes
+
+    bm = src_engine.bm
+    hashes = chain_hashes(prompt_ids)
+    n_hit = bm.peek_prefix(hashes)
+    hashes = hashes[:n_hit]
+    if not hashes:
+        return 0
+    pages = bm.match_prefix(hashes, count_stats=False)  # takes a reference on each page
+    try:
+        spool, dpool = src_engine.runner.pool, receiver.engine.runner.pool
+        page_bytes = spool.stride(0) * spool.element_size()
+        res = receiver.reserve(hashes, page_bytes)
+        missing, dst = res["missing"], res["pages"]
+        idx = {h: i for i, h in enumerate(hashes)}
+        src = [pages[idx[h]] for h in missing]
+        if missing and spool.is_cuda:
+            n = len(src)
+            sp = (ctypes.c_int64 * n)(*src)
+            dp = (ctypes.c_int64 * n)(*dst)
+            stream = torch.cuda.Stream(device=spool.device)
+            stream.wait_stream(torch.cuda.current_stream())
+            rc = comm().comm_push_pages(c_void_p(spool.data_ptr()), c_void_p(dpool.data_ptr()),
+                                        page_bytes, sp, dp, n, c_void_p(stream.cuda_stream))
+            if rc != 0:
+                raise RuntimeError(f"comm_push_pages failed ({rc})")
+            stream.synchronize()
+        elif missing:
+            dpool[torch.tensor(dst)] = spool[torch.tensor(src)]
+        if missing:
+            receiver.commit(missing, dst)
+        return len(missing)
+    finally:
+        bm.free(pages)
