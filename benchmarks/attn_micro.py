@@ -1,0 +1,131 @@
+"""Kernel-level benchmark of the paged attention kernels at the multi-round-QA shapes
+(Llama-3-8B geometry: 32 query heads, 8 KV heads, head_dim 128, 64-token pages).
+
+Cases (one JSON line each):
+  prefill_cold   one sequence, an 8192-token chunk behind an 8192-token cached prefix
+  prefill_warm   40 sequences, 128 new tokens each behind ~21k cached tokens (a follow-up turn)
+  decode         40 sequences, one token each, ~21.5k-token contexts (distinct pages)
+
+Every timed launch touches far more KV than the 256 MiB Infinity Cache holds, inputs are random
+(never zero-filled), and variants are timed interleaved in one process.
+
+    python benchmarks/attn_micro.py [--iters 10] [--cases prefill_cold,prefill_warm,decode]
+"""
+
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from vllm_production_stack_amd import ops  # noqa: E402
+
+N_Q, N_KV, HD, PAGE = 32, 8, 128, 64
+DEV = "cuda"
+
+
+def make_pool(pages: int, seed: int = 0) -> torch.Tensor:
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    pool = torch.empty((pages, 1, 2, N_KV, PAGE * HD), device=DEV, dtype=torch.bfloat16)
+    pool.normal_(0.0, 1.0, generator=g)
+    return pool
+
+
+def timed(fn, iters: int) -> float:
+    """Median milliseconds per call."""
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def prefill_case(name: str, n_seqs: int, q_len: int, prefix: int, iters: int,
+                 variants=(0, 1, 2)) -> dict:
+    ctx = prefix + q_len
+    pages_per_seq = (ctx + PAGE - 1) // PAGE
+    pool = make_pool(n_seqs * pages_per_seq + 1)
+    g = torch.Generator().manual_seed(1)
+    perm = torch.randperm(n_seqs * pages_per_seq, generator=g).view(n_seqs, pages_per_seq)
+    bt = perm.to(torch.int32).to(DEV)
+    q = torch.randn((n_seqs * q_len, N_Q * HD), device=DEV).to(torch.bfloat16)
+    out = torch.empty_like(q)
+    cu = torch.arange(0, (n_seqs + 1) * q_len, q_len, dtype=torch.int32, device=DEV)
+    ctxs = torch.full((n_seqs,), ctx, dtype=torch.int32, device=DEV)
+    ts, tq = ops.build_prefill_tiles([q_len] * n_seqs, N_Q, N_KV)
+    ts = torch.tensor(ts, dtype=torch.int32, device=DEV)
+    tq = torch.tensor(tq, dtype=torch.int32, device=DEV)
+    scale = HD ** -0.5
+
+    def run():
+        ops.paged_prefill(q, out, pool, 0, bt, cu, ctxs, ts, tq, N_Q, N_KV, HD, scale)
+
+    keys = sum(prefix + i + 1 for i in range(q_len)) * n_seqs  # causal (query, key) pairs
+    flops = 4.0 * keys * HD * N_Q
+    res = {"case": name, "n_seqs": n_seqs, "q_len": q_len, "prefix": prefix}
+    # variants interleaved in one process: round-robin over the kernel generations
+    samples = {v: [] for v in variants}
+    for _ in range(3):
+        for v in variants:
+            ops.set_prefill_variant(v)
+            samples[v].append(timed(run, iters))
+    for v in variants:
+        ms = sorted(samples[v])[1]
+        res[f"variant{v}"] = {"ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 1)}
+    ops.set_prefill_variant(2)
+    return res
+
+
+def decode_case(n_seqs: int, ctx: int, iters: int) -> dict:
+    pages_per_seq = (ctx + PAGE - 1) // PAGE
+    pool = make_pool(n_seqs * pages_per_seq + 1)
+    g = torch.Generator().manual_seed(2)
+    perm = torch.randperm(n_seqs * pages_per_seq, generator=g).view(n_seqs, pages_per_seq)
+    bt = perm.to(torch.int32).to(DEV)
+    q = torch.randn((n_seqs, N_Q * HD), device=DEV).to(torch.bfloat16)
+    out = torch.empty_like(q)
+    ctxs = torch.full((n_seqs,), ctx, dtype=torch.int32, device=DEV)
+    scale = HD ** -0.5
+    res = {"case": "decode", "n_seqs": n_seqs, "ctx": ctx}
+    kv_bytes = n_seqs * ctx * N_KV * HD * 2 * 2
+    for splits in sorted({1, 2, 3, 4, 6, 8, ops.decode_num_splits(n_seqs, N_KV, ctx)}):
+        ws_o = torch.empty((n_seqs, N_Q, splits, HD), dtype=torch.float32, device=DEV)
+        ws_ml = torch.empty((n_seqs, N_Q, splits, 2), dtype=torch.float32, device=DEV)
+
+        def run():
+            ops.paged_decode(q, out, pool, 0, bt, ctxs, N_Q, N_KV, HD, scale, splits, ws_o, ws_ml)
+
+        ms = timed(run, iters)
+        res[f"splits{splits}"] = {"ms": round(ms, 4), "tb_per_s": round(kv_bytes / ms / 1e9, 3)}
+    res["default_splits"] = ops.decode_num_splits(n_seqs, N_KV, ctx)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--cases", default="prefill_cold,prefill_warm,decode")
+    ap.add_argument("--variants", default="0,1,2", help="prefill kernel generations to time")
+    a = ap.parse_args()
+    cases = a.cases.split(",")
+    variants = tuple(int(v) for v in a.variants.split(","))
+    if "prefill_cold" in cases:
+        print(json.dumps(prefill_case("prefill_cold", 1, 8192, 8192, a.iters, variants)), flush=True)
+    if "prefill_warm" in cases:
+        print(json.dumps(prefill_case("prefill_warm", 40, 128, 21000, a.iters, variants)), flush=True)
+    if "decode" in cases:
+        print(json.dumps(decode_case(40, 21500, a.iters)), flush=True)
+
+
+if __name__ == "__main__":
+    main()

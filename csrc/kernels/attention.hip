@@ -231,6 +231,245 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Second-generation prefill kernel.  Same work decomposition, operand layouts and LDS
+// images as paged_prefill_kernel above; what changes is the schedule around the MFMAs:
+//   * two LDS buffers (64 KiB per workgroup, two workgroups per CU): the next tile is
+//     written into the other buffer at the top of an iteration, so one barrier per
+//     64-key tile instead of two, and the global loads run two tiles ahead;
+//   * softmax in the scaled base-2 domain straight off the raw scores: one fma + one
+//     exp2 per probability, the row maximum taken on raw scores (max3-shaped);
+//   * the O rescale is skipped (wave-uniform) while no row's maximum grew by more than
+//     LAZY_THR in the base-2 domain: probabilities then stay <= 2^LAZY_THR, O and l
+//     keep the same reference maximum, and O / l is unchanged;
+//   * causal masking only on tiles that cross this wave's diagonal.
+// ---------------------------------------------------------------------------------
+#define LAZY_THR 6.0f
+
+template <bool PRIO>
+__global__ __launch_bounds__(256, 2) void paged_prefill_kernel_v2(
+    const uint16_t* __restrict__ q, long q_stride, uint16_t* __restrict__ out, long out_stride,
+    const uint16_t* __restrict__ cache, long page_stride, long v_offset,
+    const int* __restrict__ block_tables, int max_blocks, const int* __restrict__ cu_q,
+    const int* __restrict__ ctx_lens, const int* __restrict__ tile_seq,
+    const int* __restrict__ tile_q0, int n_q, int n_kv, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // 2 x (16 KiB K + 16 KiB V)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31;
+  const int h = lane >> 5;
+
+  const int G = n_q / n_kv;
+  const int GP = G < 4 ? G : 4;
+  const int groups_per_kv = G / GP;
+  const int kvh = blockIdx.y / groups_per_kv;
+  const int hg = blockIdx.y % groups_per_kv;
+  const int head = kvh * G + hg * GP + (wave % GP);
+  const int qsub = wave / GP;
+
+  const int seq = tile_seq[blockIdx.x];
+  const int q0 = tile_q0[blockIdx.x];
+  const int row0 = cu_q[seq];
+  const int q_len = cu_q[seq + 1] - row0;
+  const int ctx = ctx_lens[seq];
+  const int pos0 = ctx - q_len;
+  const int QT = 32 * (4 / GP);
+
+  const int wq0 = q0 + qsub * 32;
+  const int my_row = wq0 + r;
+  const bool row_ok = my_row < q_len;
+  const int my_pos = row_ok ? pos0 + my_row : ctx - 1;
+  int w_last = wq0 + 31;
+  if (w_last > q_len - 1) w_last = q_len - 1;
+  const bool wave_ok = wq0 < q_len;
+  const int w_max_pos = pos0 + w_last;
+  const int w_min_pos = pos0 + wq0;
+  int b_last = q0 + QT - 1;
+  if (b_last > q_len - 1) b_last = q_len - 1;
+  const int n_tiles = (pos0 + b_last) / PAGE + 1;
+
+  bf16x8 qf[8];
+  {
+    const uint16_t* qp = q + (long)(row0 + (row_ok ? my_row : 0)) * q_stride + head * HEAD_DIM + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + 16 * ks);
+      if (!row_ok) v = (u32x4){0, 0, 0, 0};
+      qf[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+
+  const int* bt = block_tables + (long)seq * max_blocks;
+  const long kv_head_off = (long)kvh * PAGE * HEAD_DIM;
+
+  u32x4 sk[4], sv[4];
+  auto stage_load = [&](int tile) {
+    const long page = bt[tile];
+    const uint16_t* kp = cache + page * page_stride + kv_head_off + tid * 8;
+    const uint16_t* vp = kp + v_offset;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sk[i] = *reinterpret_cast<const u32x4*>(kp + i * 2048);
+      sv[i] = *reinterpret_cast<const u32x4*>(vp + i * 2048);
+    }
+  };
+  // per-thread LDS write offsets (same swizzled images as the first-generation kernel)
+  int wk_off[4], wv_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = i * 256 + tid;
+    const int key = id >> 4, c = id & 15;
+    wk_off[i] = key * 256 + ((c ^ (key & 15)) << 4);
+    const int d = id >> 3, cv = id & 7;
+    wv_off[i] = 16384 + d * 128 + ((cv ^ ((d >> 1) & 7)) << 4);
+  }
+  auto stage_write = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4*>(buf + wk_off[i]) = sk[i];
+      *reinterpret_cast<u32x4*>(buf + wv_off[i]) = sv[i];
+    }
+  };
+
+  f32x16 o_acc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o_acc[dt][i] = 0.f;
+  float m_run = NEG_BIG;  // reference maximum, scaled base-2 domain
+  float l_run = 0.f;
+
+  const int krow = (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1);
+  // K read offsets: row (32 tt + krow), chunk (2 ks + h) ^ (row & 15)
+  const int k_sw = krow & 15;  // (32 tt + krow) & 15 == krow & 15
+  const int k_row_off = krow * 256;
+
+  stage_load(0);
+  stage_write(lds);
+  if (n_tiles > 1) stage_load(1);
+  __syncthreads();
+
+  for (int t = 0; t < n_tiles; ++t) {
+    char* cur = lds + ((t & 1) << 15);
+    if (t + 1 < n_tiles) {
+      stage_write(lds + (((t + 1) & 1) << 15));
+      if (t + 2 < n_tiles) stage_load(t + 2);
+    }
+
+    const int kbase = t * PAGE;
+    if (wave_ok && kbase <= w_max_pos) {
+      const char* lk = cur;
+      const char* lv = cur + 16384;
+      f32x16 s_acc[2];
+      if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s_acc[tt][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          bf16x8 a = lds_read_frag(lk, tt * 8192 + k_row_off + (((2 * ks + h) ^ k_sw) << 4));
+          s_acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s_acc[tt], 0, 0, 0);
+        }
+      }
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
+
+      // accumulator reg i of half h = key kbase + 32 tt + 16 (i>>3) + 8 h + (i&7)
+      if ((kbase + PAGE - 1) > w_min_pos) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = kbase + 32 * tt + 16 * (i >> 3) + 8 * h + (i & 7);
+            if (key > my_pos) s_acc[tt][i] = NEG_BIG;
+          }
+      }
+      float mx0 = fmaxf(s_acc[0][0], s_acc[1][0]);
+      float mx1 = fmaxf(s_acc[0][1], s_acc[1][1]);
+#pragma unroll
+      for (int i = 2; i < 16; i += 2) {
+        mx0 = fmaxf(fmaxf(mx0, s_acc[0][i]), s_acc[1][i]);
+        mx1 = fmaxf(fmaxf(mx1, s_acc[0][i + 1]), s_acc[1][i + 1]);
+      }
+      float mx = fmaxf(mx0, mx1);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      // masked entries are NEG_BIG: keep the product finite and far below any real score
+      const float m_tile = fmaxf(mx * scale_log2e, NEG_BIG);
+      const bool grow = m_tile > m_run + LAZY_THR;
+      if (__any(grow)) {
+        const float m_new = fmaxf(m_run, m_tile);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o_acc[dt][i] *= alpha;
+      }
+      float ps0 = 0.f, ps1 = 0.f;
+      bf16x8 pf[4];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          u32x4 pk;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const float p0 = __builtin_amdgcn_exp2f(
+                __builtin_fmaf(s_acc[tt][8 * s + 2 * jj], scale_log2e, -m_run));
+            const float p1 = __builtin_amdgcn_exp2f(
+                __builtin_fmaf(s_acc[tt][8 * s + 2 * jj + 1], scale_log2e, -m_run));
+            ps0 += p0;
+            ps1 += p1;
+            pk[jj] = pack_bf16x2(p0, p1);
+          }
+          pf[tt * 2 + s] = __builtin_bit_cast(bf16x8, pk);
+        }
+      l_run += ps0 + ps1;
+      if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int d = 32 * dt + r;
+        const int rowoff = d * 128;
+        const int sw = (d >> 1) & 7;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          bf16x8 a = lds_read_frag(lv, rowoff + (((2 * kk + h) ^ sw) << 4));
+          o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[kk], o_acc[dt], 0, 0, 0);
+        }
+      }
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (row_ok) {
+    const float inv = 1.f / l_tot;
+    uint16_t* op = out + (long)(row0 + my_row) * out_stride + head * HEAD_DIM;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        u32x2 w;
+        w[0] = pack_bf16x2(o_acc[dt][4 * g4] * inv, o_acc[dt][4 * g4 + 1] * inv);
+        w[1] = pack_bf16x2(o_acc[dt][4 * g4 + 2] * inv, o_acc[dt][4 * g4 + 3] * inv);
+        *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g4 + 4 * h) = w;
+      }
+  }
+}
+
+// Kernel selection for in-process A/B timing (0 = first generation, 1 = second generation,
+// 2 = second generation with raised wave priority around the MFMA clusters).
+static int g_prefill_variant = 2;
+VPSA_EXPORT int vpsa_set_prefill_variant(int v) {
+  const int old = g_prefill_variant;
+  g_prefill_variant = v;
+  return old;
+}
+
 VPSA_EXPORT int vpsa_paged_prefill(const void* q, long q_stride, void* out, long out_stride,
                                    const void* cache, long page_stride, long v_offset,
                                    const int* block_tables, int max_blocks, const int* cu_q,
@@ -244,10 +483,21 @@ VPSA_EXPORT int vpsa_paged_prefill(const void* q, long q_stride, void* out, long
   if (G == 3) return -1;
   const int GP = G < 4 ? G : 4;
   dim3 grid(num_tiles, n_kv * (G / GP)), block(256);
-  hipLaunchKernelGGL(paged_prefill_kernel, grid, block, 32768, stream, (const uint16_t*)q,
-                     q_stride, (uint16_t*)out, out_stride, (const uint16_t*)cache, page_stride,
-                     v_offset, block_tables, max_blocks, cu_q, ctx_lens, tile_seq, tile_q0, n_q,
-                     n_kv, scale * 1.4426950408889634f);
+  const float sl2 = scale * 1.4426950408889634f;
+#define VPSA_PREFILL_ARGS                                                                      \
+  (const uint16_t*)q, q_stride, (uint16_t*)out, out_stride, (const uint16_t*)cache,             \
+      page_stride, v_offset, block_tables, max_blocks, cu_q, ctx_lens, tile_seq, tile_q0, n_q,  \
+      n_kv, sl2
+  if (g_prefill_variant == 0) {
+    hipLaunchKernelGGL(paged_prefill_kernel, grid, block, 32768, stream, VPSA_PREFILL_ARGS);
+  } else if (g_prefill_variant == 2) {
+    hipLaunchKernelGGL(paged_prefill_kernel_v2<true>, grid, block, 65536, stream,
+                       VPSA_PREFILL_ARGS);
+  } else {
+    hipLaunchKernelGGL(paged_prefill_kernel_v2<false>, grid, block, 65536, stream,
+                       VPSA_PREFILL_ARGS);
+  }
+#undef VPSA_PREFILL_ARGS
   return 0;
 }
 

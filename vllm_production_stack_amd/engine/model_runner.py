@@ -203,7 +203,7 @@ class ModelRunner:
             "bt": torch.zeros((bsz, mp), dtype=torch.int32, device=dev),
             "ctx": torch.zeros(bsz, dtype=torch.int32, device=dev),
         }
-        splits = max(1, min(32, 1024 // max(1, bsz * self.n_kv_local)))
+        splits = ops.decode_num_splits(bsz, self.n_kv_local, self.max_model_len)
         mc = self.model_cfg
         ws_o = torch.empty((bsz, self.model.n_q, splits, mc.head_dim), dtype=torch.float32, device=dev)
         ws_ml = torch.empty((bsz, self.model.n_q, splits, 2), dtype=torch.float32, device=dev)
