@@ -1,0 +1,121 @@
+"""Tensor- and pipeline-parallel replicas on CPU (gloo, several processes): every layout must
+generate exactly what the single-process engine generates from the same seed, and worker ranks
+must leave their loop when the driver shuts down."""
+
+import copy
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from vllm_production_stack_amd.engine.config import EngineConfig
+from vllm_production_stack_amd.engine.request import SamplingParams
+
+SP = SamplingParams(max_tokens=6, temperature=0, ignore_eos=True)
+
+
+def _prompts():
+    g = torch.Generator().manual_seed(11)
+    return [torch.randint(16, 500, (n,), generator=g).tolist() for n in (150, 70, 9)]
+
+
+def _cfg(model, **kw):
+    return EngineConfig(model=model, device="cpu", dtype="float32", max_model_len=1024,
+                        max_num_seqs=8, max_num_batched_tokens=128, num_gpu_blocks_override=48,
+                        port=0, **kw)
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, model, tp, pp, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from vllm_production_stack_amd.engine.llm_engine import LLMEngine
+    from vllm_production_stack_amd.parallel.launch import init_parallel_from_env
+    from vllm_production_stack_amd.parallel.state import get_replica
+
+    init_parallel_from_env(tp, pp)
+    eng = LLMEngine(_cfg(model, tensor_parallel_size=tp, pipeline_parallel_size=pp))
+    if get_replica().is_driver:
+        outs = eng.generate(_prompts(), copy.deepcopy(SP))
+        # a second wave through the prefix cache and a chunked prefill (budget 128 < 150 rows)
+        outs2 = eng.generate(_prompts()[:1], copy.deepcopy(SP))
+        q.put((outs, outs2))
+        eng.shutdown()
+    else:
+        eng.runner.worker_loop()
+        q.put(("worker-exit", rank))
+    import torch.distributed as dist
+
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_layout(model, tp, pp):
+    world = tp * pp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, model, tp, pp, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue as _queue
+    import time as _time
+
+    got, deadline = [], _time.time() + 240
+    while len(got) < world:
+        try:
+            got.append(q.get(timeout=1))
+        except _queue.Empty:
+            dead = [p for p in procs if p.exitcode not in (None, 0)]
+            if dead or _time.time() > deadline:
+                for p in procs:
+                    p.kill()
+                raise AssertionError(f"rank process failed or timed out (exit codes {[p.exitcode for p in procs]})")
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    result = [g for g in got if g[0] != "worker-exit"]
+    assert len(result) == 1 and len(got) == world
+    return result[0]
+
+
+def _single(model):
+    from vllm_production_stack_amd.engine.llm_engine import LLMEngine
+    from vllm_production_stack_amd.parallel.state import reset_parallel_state
+
+    reset_parallel_state()
+    eng = LLMEngine(_cfg(model))
+    outs = eng.generate(_prompts(), copy.deepcopy(SP))
+    outs2 = eng.generate(_prompts()[:1], copy.deepcopy(SP))
+    return outs, outs2
+
+
+@pytest.mark.parametrize("model,tp,pp", [
+    ("tiny-llama-gqa", 2, 1),
+    ("tiny-llama-gqa", 1, 3),
+    ("tiny-llama-gqa", 2, 2),
+    ("tiny-mixtral", 2, 1),
+])
+def test_parallel_layout_matches_single_process(model, tp, pp):
+    want = _single(model)
+    got = _run_layout(model, tp, pp)
+    assert got[0] == want[0]
+    assert got[1] == want[1]
+
+
+def test_layer_ranges_cover_model():
+    from vllm_production_stack_amd.parallel.state import PPGroup
+
+    for layers in (3, 32, 33):
+        for size in (1, 2, 3, 4):
+            spans = [PPGroup(rank=r, size=size).layer_range(layers) for r in range(size)]
+            assert spans[0][0] == 0 and spans[-1][1] == layers
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))

@@ -94,11 +94,23 @@ async def run_server(cfg: EngineConfig, ready: "asyncio.Event | None" = None) ->
     from .llm_engine import LLMEngine
     from .server import serve
 
-    if cfg.tensor_parallel_size > 1:
-        from ..parallel.launch import init_tp_from_env
+    world = cfg.tensor_parallel_size * max(1, cfg.pipeline_parallel_size)
+    if world > 1:
+        from ..parallel.launch import init_parallel_from_env
 
-        init_tp_from_env(cfg.tensor_parallel_size)
+        init_parallel_from_env(cfg.tensor_parallel_size, max(1, cfg.pipeline_parallel_size))
+        if cfg.enable_lora:
+            raise ValueError("--enable-lora needs a single-process replica (tp = pp = 1)")
     engine = LLMEngine(cfg)
+    if world > 1:
+        from ..parallel.state import get_replica
+
+        if not get_replica().is_driver:
+            # worker rank: no HTTP front, no scheduler; execute the driver's step plans
+            if ready is not None:
+                ready.set()
+            await asyncio.get_running_loop().run_in_executor(None, engine.runner.worker_loop)
+            return
     if cfg.enable_lora:
         from .lora import LoRAManager
 

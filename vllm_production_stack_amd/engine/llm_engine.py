@@ -59,6 +59,11 @@ class LLMEngine:
         kvt = self.cfg.kv_transfer
         if not (off.enabled or off.enable_pd or off.enable_controller or (kvt and kvt.kv_connector)):
             return
+        if self.runner.distributed:
+            # the pool of a tp/pp replica is sharded by KV head and by layer across processes;
+            # the tiers move whole pages of one process's pool
+            log.warning("KV offload / transfer tiers are disabled for tensor/pipeline-parallel replicas")
+            return
         from ..kv.connector import KVConnector
 
         self.connector = KVConnector(self, off, kvt)
@@ -196,3 +201,4 @@ class LLMEngine:
     def shutdown(self) -> None:
         if self.connector is not None:
             self.connector.close()
+        self.runner.stop_workers()

@@ -7,6 +7,12 @@ contiguous run: offload / peer transfer of a page is a single large copy.
 
 Decode-only steps replay a HIP graph captured per padded batch size (the launch-bound
 inner loop: ~10 launches per layer); mixed and prefill steps run eagerly.
+
+Tensor / pipeline parallel replicas (one process per GPU): the driver rank turns the
+scheduler output into a host-side *plan* (plain lists), broadcasts it to the replica's
+ranks, and every rank materialises the same batch and runs its shard / stage of the model.
+Worker ranks sit in ``worker_loop``.  Logits are produced on the first pipeline stage (it
+holds the vocab-parallel LM head); the last stage returns the normed hidden rows to it.
 """
 
 from __future__ import annotations
@@ -19,7 +25,8 @@ import torch
 from .. import ops
 from ..models.batch import BatchMeta
 from ..models.loader import build_model
-from ..parallel.state import get_tp
+from ..parallel.state import (get_pp, get_replica, get_tp, pp_recv, pp_send, replica_broadcast,
+                              replica_min_int)
 from .block_manager import PAGE
 from .config import EngineConfig, ModelConfig
 from .sampler import Sampler
@@ -46,15 +53,20 @@ class ModelRunner:
         log.info("model %s ready: %.2f GiB weights in %.1fs", model_cfg.name,
                  self.model.weight_bytes() / 2**30, time.time() - t0)
         self.n_kv_local = self.model.n_kv
-        self.page_elems = model_cfg.num_layers * 2 * self.n_kv_local * PAGE * model_cfg.head_dim
+        self.replica = get_replica()
+        self.distributed = self.replica.size > 1
+        # layers whose KV this rank holds (its pipeline stage)
+        self.n_layers_local = len(self.model.layers)
+        self.page_elems = self.n_layers_local * 2 * self.n_kv_local * PAGE * model_cfg.head_dim
         self.page_bytes = self.page_elems * torch.empty((), dtype=self.dtype).element_size()
         self.max_pages_per_seq = (self.max_model_len + PAGE - 1) // PAGE
         self.num_pages = self._plan_pages()
         self.pool = torch.zeros(
-            (self.num_pages, model_cfg.num_layers, 2, self.n_kv_local, PAGE * model_cfg.head_dim),
+            (self.num_pages, self.n_layers_local, 2, self.n_kv_local, PAGE * model_cfg.head_dim),
             dtype=self.dtype, device=device)
         self.sampler = Sampler(device, cfg.seed)
-        self.use_graphs = device.type == "cuda" and not cfg.enforce_eager
+        # collectives and stage hand-offs run eagerly: graphs only for single-process replicas
+        self.use_graphs = device.type == "cuda" and not cfg.enforce_eager and not self.distributed
         self._graphs: dict[int, dict] = {}
         self._graph_pool = None
         self._pin = device.type == "cuda"
@@ -65,6 +77,9 @@ class ModelRunner:
     def _plan_pages(self) -> int:
         if self.cfg.num_gpu_blocks_override:
             return int(self.cfg.num_gpu_blocks_override)
+        return replica_min_int(self._plan_pages_local())
+
+    def _plan_pages_local(self) -> int:
         mc = self.model_cfg
         if self.device.type != "cuda":
             # CPU replicas: a modest pool (enough for max_num_seqs short sequences)
@@ -94,7 +109,9 @@ class ModelRunner:
             return t.pin_memory().to(self.device, non_blocking=True)
         return t
 
-    def _build(self, decodes: list[ScheduledSeq], prefills: list[ScheduledSeq]):
+    def _plan(self, decodes: list[ScheduledSeq], prefills: list[ScheduledSeq]):
+        """Host-side description of the step (plain lists: cheap to broadcast to worker ranks)
+        and the sequences that sample, in logits-row order."""
         ids: list[int] = []
         pos: list[int] = []
         slots: list[int] = []
@@ -124,38 +141,74 @@ class ModelRunner:
             if s.samples:
                 logits_rows.append(row - 1)
                 sample_seqs.append(s)
-        meta = BatchMeta(positions=self._to_dev(pos, torch.int32),
-                         slots=self._to_dev(slots, torch.int64), num_decode=len(decodes),
-                         num_prefill_seqs=len(prefills))
+        plan = {"ids": ids, "pos": pos, "slots": slots, "logits_rows": logits_rows,
+                "num_decode": len(decodes), "num_prefill": len(prefills)}
         if decodes:
-            width = max(len(s.req.pages) for s in decodes)
-            bt = [s.req.pages + [0] * (width - len(s.req.pages)) for s in decodes]
-            meta.dec_block_tables = self._to_dev(bt, torch.int32)
-            ctx = [s.start + 1 for s in decodes]
-            meta.dec_ctx_lens = self._to_dev(ctx, torch.int32)
-            meta.dec_num_splits = ops.decode_num_splits(len(decodes), self.n_kv_local, max(ctx))
+            plan["dec_pages"] = [s.req.pages for s in decodes]
+            plan["dec_ctx"] = [s.start + 1 for s in decodes]
         if prefills:
-            width = max(len(s.req.pages) for s in prefills)
-            bt = [s.req.pages + [0] * (width - len(s.req.pages)) for s in prefills]
-            meta.pre_block_tables = self._to_dev(bt, torch.int32)
-            q_lens = [s.n for s in prefills]
-            cu = [0]
-            for q in q_lens:
-                cu.append(cu[-1] + q)
-            meta.pre_cu_q = self._to_dev(cu, torch.int32)
-            meta.pre_ctx_lens = self._to_dev([s.start + s.n for s in prefills], torch.int32)
-            if self.device.type == "cuda":
-                ts, tq = ops.build_prefill_tiles(q_lens, self.model.n_q, self.model.n_kv)
-                meta.pre_tile_seq = self._to_dev(ts, torch.int32)
-                meta.pre_tile_q0 = self._to_dev(tq, torch.int32)
-        meta.logits_rows = self._to_dev(logits_rows, torch.int64) if logits_rows else None
+            plan["pre_pages"] = [s.req.pages for s in prefills]
+            plan["q_lens"] = [s.n for s in prefills]
+            plan["pre_ctx"] = [s.start + s.n for s in prefills]
         if self.model.lora is not None:
             lslots = [s.req.lora_slot for s in decodes]
             for s in prefills:
                 lslots.extend([s.req.lora_slot] * s.n)
             if any(x >= 0 for x in lslots):
-                meta.lora_slots = self._to_dev(lslots, torch.int64)
-        return self._to_dev(ids, torch.int64), meta, sample_seqs
+                plan["lora_slots"] = lslots
+        return plan, sample_seqs
+
+    def _materialize(self, plan: dict):
+        """Plan -> device tensors (input ids + BatchMeta)."""
+        meta = BatchMeta(positions=self._to_dev(plan["pos"], torch.int32),
+                         slots=self._to_dev(plan["slots"], torch.int64),
+                         num_decode=plan["num_decode"], num_prefill_seqs=plan["num_prefill"])
+        if plan["num_decode"]:
+            pages = plan["dec_pages"]
+            width = max(len(p) for p in pages)
+            meta.dec_block_tables = self._to_dev([p + [0] * (width - len(p)) for p in pages], torch.int32)
+            ctx = plan["dec_ctx"]
+            meta.dec_ctx_lens = self._to_dev(ctx, torch.int32)
+            meta.dec_num_splits = ops.decode_num_splits(len(ctx), self.n_kv_local, max(ctx))
+        if plan["num_prefill"]:
+            pages = plan["pre_pages"]
+            width = max(len(p) for p in pages)
+            meta.pre_block_tables = self._to_dev([p + [0] * (width - len(p)) for p in pages], torch.int32)
+            q_lens = plan["q_lens"]
+            cu = [0]
+            for q in q_lens:
+                cu.append(cu[-1] + q)
+            meta.pre_cu_q = self._to_dev(cu, torch.int32)
+            meta.pre_ctx_lens = self._to_dev(plan["pre_ctx"], torch.int32)
+            if self.device.type == "cuda":
+                ts, tq = ops.build_prefill_tiles(q_lens, self.model.n_q, self.model.n_kv)
+                meta.pre_tile_seq = self._to_dev(ts, torch.int32)
+                meta.pre_tile_q0 = self._to_dev(tq, torch.int32)
+        rows = plan["logits_rows"]
+        meta.logits_rows = self._to_dev(rows, torch.int64) if rows else None
+        if plan.get("lora_slots") is not None:
+            meta.lora_slots = self._to_dev(plan["lora_slots"], torch.int64)
+        return self._to_dev(plan["ids"], torch.int64), meta
+
+    def _run_plan(self, plan: dict):
+        """Every rank of the replica: run this rank's part of the step.  Returns the logits
+        ([num_out, vocab]) on first-stage ranks when the step samples, else ``None``."""
+        ids, meta = self._materialize(plan)
+        hidden = self.model.forward(ids, self.pool, meta)
+        n_out = len(plan["logits_rows"])
+        if n_out == 0:
+            return None, None
+        pp = get_pp()
+        if pp.size > 1:
+            # the last stage hands the normed rows back to the first (same tensor-parallel shard)
+            if pp.is_last:
+                pp_send(hidden, pp.first)
+                hidden = None
+            elif pp.is_first:
+                hidden = pp_recv((n_out, self.model_cfg.hidden_size), self.dtype, self.device, pp.last)
+        if not pp.is_first:
+            return None, None
+        return hidden, self.model.compute_logits(hidden)
 
     # ------------------------------------------------------------------ execution
     @torch.inference_mode()
@@ -175,16 +228,47 @@ class ModelRunner:
                 and all(s.samples for s in out.decodes)
                 and len(out.decodes) <= _GRAPH_BUCKETS[-1]):
             return self._execute_decode_graph(out.decodes)
-        ids, meta, sample_seqs = self._build(out.decodes, out.prefills)
-        hidden = self.model.forward(ids, self.pool, meta)
+        plan, sample_seqs = self._plan(out.decodes, out.prefills)
+        if self.distributed:
+            replica_broadcast(("step", plan))
+        hidden, logits = self._run_plan(plan)
         if not sample_seqs:
             return []
         for i, s in enumerate(sample_seqs):
             if s.req.pooling:
                 s.req.pooled = hidden[i].float().cpu()
-        logits = self.model.compute_logits(hidden)
         toks, infos = self.sampler.sample(logits, [s.req for s in sample_seqs])
         return list(zip(sample_seqs, toks, infos))
+
+    # ------------------------------------------------------------------ worker ranks
+    def worker_loop(self) -> None:
+        """Non-driver ranks of a tensor/pipeline-parallel replica: execute what the driver
+        broadcasts until it says stop."""
+        assert self.distributed and not self.replica.is_driver
+        with torch.inference_mode():
+            while True:
+                msg = replica_broadcast(None)
+                kind = msg[0]
+                if kind == "stop":
+                    return
+                if kind == "step":
+                    self._run_plan(msg[1])
+                elif kind == "sleep":
+                    self._sleep_local(msg[1])
+                elif kind == "wake":
+                    self._wake_local()
+                elif kind == "call":
+                    getattr(self, msg[1])(*msg[2])
+
+    def stop_workers(self) -> None:
+        if self.distributed and self.replica.is_driver:
+            replica_broadcast(("stop",))
+
+    def replica_call(self, method: str, *args):
+        """Run ``self.<method>(*args)`` on every rank of the replica (driver side)."""
+        if self.distributed:
+            replica_broadcast(("call", method, args))
+        return getattr(self, method)(*args)
 
     # ------------------------------------------------------------------ HIP-graph decode
     def _bucket(self, n: int) -> int:
@@ -272,9 +356,14 @@ class ModelRunner:
     # ------------------------------------------------------------------ sleep / wake
     def sleep(self, level: int = 1) -> int:
         """Release HBM: weights to pinned host memory (level 1) or dropped (level 2); the KV
-        pool is freed.  Returns bytes released."""
+        pool is freed.  Returns bytes released (this rank)."""
         if self.sleeping:
             return 0
+        if self.distributed:
+            replica_broadcast(("sleep", level))
+        return self._sleep_local(level)
+
+    def _sleep_local(self, level: int = 1) -> int:
         freed = 0
         self._graphs.clear()
         self._graph_pool = None
@@ -300,6 +389,11 @@ class ModelRunner:
     def wake_up(self) -> None:
         if not self.sleeping:
             return
+        if self.distributed:
+            replica_broadcast(("wake",))
+        self._wake_local()
+
+    def _wake_local(self) -> None:
         if self.device.type == "cuda":
             for t, host in self._sleep_stash:
                 shape = host.shape if host is not None else None
@@ -308,7 +402,6 @@ class ModelRunner:
                     t.set_(fresh.untyped_storage(), 0, shape, fresh.stride())
             torch.cuda.synchronize()
             if any(h is None for _, h in self._sleep_stash):
-                self.model.layers.clear()
                 self.model.init_random(self.cfg.seed)
         self._sleep_stash = []
         self.pool = torch.zeros(self._pool_shape, dtype=self.dtype, device=self.device)

@@ -74,16 +74,19 @@ def _load_llama(model: TransformerModel, ckpt_dir: Path) -> None:
     for name, t in _iter_safetensors(ckpt_dir):
         t = t.to(model.dtype)
         if name == "model.embed_tokens.weight":
+            if model.embed is None:
+                continue
             model.embed.copy_(t)
             if model.lm_head is not model.embed and cfg.tie_word_embeddings:
                 model.lm_head[: min(model.vocab_shard, t.shape[0] - r * model.vocab_shard)].copy_(
                     t[r * model.vocab_shard:(r + 1) * model.vocab_shard])
             continue
         if name == "model.norm.weight":
-            model.norm.copy_(t)
+            if model.norm is not None:
+                model.norm.copy_(t)
             continue
         if name == "lm_head.weight":
-            if model.lm_head is not model.embed:
+            if model.lm_head is not None and model.lm_head is not model.embed:
                 rows = t[r * model.vocab_shard:(r + 1) * model.vocab_shard]
                 model.lm_head[: rows.shape[0]].copy_(rows)
             continue
@@ -91,9 +94,9 @@ def _load_llama(model: TransformerModel, ckpt_dir: Path) -> None:
         if not m:
             continue
         li, sub = int(m.group(1)), m.group(2)
-        if li >= len(model.layers):
-            continue
-        lw: LayerWeights = model.layers[li]
+        if not (model.first_layer <= li < model.last_layer):
+            continue  # another pipeline stage's layer
+        lw: LayerWeights = model.layers[li - model.first_layer]
         if sub == "input_layernorm.weight":
             lw.ln1.copy_(t)
         elif sub == "post_attention_layernorm.weight":

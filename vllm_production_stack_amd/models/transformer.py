@@ -5,6 +5,9 @@ and every hot op goes through ``ops`` (hand-written gfx950 kernels on the GPU); 
 projections are library GEMMs on the matrix cores (``F.linear`` -> hipBLASLt).
 Tensor parallelism: QKV / gate-up are column-sharded by head / channel, O / down are
 row-sharded and followed by one all-reduce each; the LM head is vocab-sharded.
+Pipeline parallelism: a stage holds a contiguous run of layers (and the KV pool slices of
+exactly those layers); the residual stream (h, residual) moves stage to stage point to point;
+the first stage owns the embedding and the LM head, the last stage the final norm.
 """
 
 from __future__ import annotations
@@ -16,7 +19,8 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..engine.config import ModelConfig
-from ..parallel.state import get_tp, tp_all_gather_last_dim, tp_all_reduce
+from ..parallel.state import (get_pp, get_tp, pp_recv, pp_send, tp_all_gather_last_dim,
+                              tp_all_reduce)
 from .batch import BatchMeta
 
 
@@ -52,45 +56,86 @@ class TransformerModel:
         self.cos_sin = ops.build_cos_sin(cfg.head_dim, max_model_len, cfg.rope_theta,
                                          cfg.rope_scaling, device=device)
         self.lora = None  # LoRAManager, attached by the runner when --enable-lora
+        pp = get_pp()
+        self.pp = pp
+        self.first_layer, self.last_layer = pp.layer_range(cfg.num_layers)
 
     # ------------------------------------------------------------------ weights
+    def _rand(self, seed: int, key: int, *shape, std: float = 0.02) -> torch.Tensor:
+        """One full (unsharded) random tensor, a function of (seed, key) only."""
+        g = torch.Generator(device=self.device).manual_seed((seed * 1000003 + key) & 0x7FFFFFFF)
+        t = torch.empty(shape, dtype=self.dtype, device=self.device)
+        t.normal_(0.0, std, generator=g)
+        return t
+
     def init_random(self, seed: int = 0) -> None:
-        """Random-init weights of the exact architecture (no checkpoint needed)."""
+        """Random-init weights of the exact architecture (no checkpoint needed).
+
+        Every tensor is drawn unsharded from its own generator and then cut to this rank's
+        tensor-parallel shard / pipeline stage, so the model is the same function whatever the
+        parallel layout (that is what the multi-process equivalence tests compare)."""
         cfg = self.cfg
-        g = torch.Generator(device=self.device).manual_seed(seed + 1000 * self.tp_rank)
-        gs = torch.Generator(device=self.device).manual_seed(seed)  # replicated tensors
-
-        def rnd(*shape, std=0.02, gen=g):
-            t = torch.empty(shape, dtype=self.dtype, device=self.device)
-            t.normal_(0.0, std, generator=gen)
-            return t
-
         h, d = cfg.hidden_size, cfg.head_dim
-        self.embed = rnd(cfg.vocab_size, h, gen=gs)
-        for _ in range(cfg.num_layers):
+        r, sz = self.tp_rank, self.tp_size
+        nq, nkv, inter = self.n_q, self.n_kv, self.inter
+
+        def rows(t, n):  # n rows per rank
+            return t[r * n:(r + 1) * n]
+
+        self.layers = []
+        self.embed = self._rand(seed, 1, cfg.vocab_size, h) if self.pp.is_first else None
+        for li in range(self.first_layer, self.last_layer):
+            k = 64 * (li + 1)
             lw = LayerWeights()
             lw.ln1 = torch.ones(h, dtype=self.dtype, device=self.device)
             lw.ln2 = torch.ones(h, dtype=self.dtype, device=self.device)
-            lw.wqkv = rnd((self.n_q + 2 * self.n_kv) * d, h)
-            lw.wo = rnd(h, self.n_q * d)
+            wq = self._rand(seed, k + 0, cfg.num_heads * d, h)
+            wk = self._rand(seed, k + 1, cfg.num_kv_heads * d, h)
+            wv = self._rand(seed, k + 2, cfg.num_kv_heads * d, h)
+            lw.wqkv = torch.cat([rows(wq, nq * d), rows(wk, nkv * d), rows(wv, nkv * d)]).contiguous()
+            del wq, wk, wv
+            wo = self._rand(seed, k + 3, h, cfg.num_heads * d)
+            lw.wo = wo[:, r * nq * d:(r + 1) * nq * d].contiguous()
+            del wo
             if cfg.num_experts > 0:
-                lw.router = rnd(cfg.num_experts, h, gen=gs)
-                lw.w13 = rnd(cfg.num_experts, 2 * self.inter, h)
-                lw.w2 = rnd(cfg.num_experts, h, self.inter)
+                lw.router = self._rand(seed, k + 4, cfg.num_experts, h)
+                w13, w2 = [], []
+                for ex in range(cfg.num_experts):
+                    g_ = self._rand(seed, k + 8 + 3 * ex, cfg.intermediate_size, h)
+                    u_ = self._rand(seed, k + 9 + 3 * ex, cfg.intermediate_size, h)
+                    d_ = self._rand(seed, k + 10 + 3 * ex, h, cfg.intermediate_size)
+                    w13.append(torch.cat([rows(g_, inter), rows(u_, inter)]))
+                    w2.append(d_[:, r * inter:(r + 1) * inter])
+                    del g_, u_, d_
+                lw.w13 = torch.stack(w13).contiguous()
+                lw.w2 = torch.stack(w2).contiguous()
             else:
-                lw.w_gate_up = rnd(2 * self.inter, h)
-                lw.w_down = rnd(h, self.inter)
+                g_ = self._rand(seed, k + 4, cfg.intermediate_size, h)
+                u_ = self._rand(seed, k + 5, cfg.intermediate_size, h)
+                lw.w_gate_up = torch.cat([rows(g_, inter), rows(u_, inter)]).contiguous()
+                del g_, u_
+                d_ = self._rand(seed, k + 6, h, cfg.intermediate_size)
+                lw.w_down = d_[:, r * inter:(r + 1) * inter].contiguous()
+                del d_
             self.layers.append(lw)
-        self.norm = torch.ones(h, dtype=self.dtype, device=self.device)
-        if cfg.tie_word_embeddings and self.tp_size == 1:
+        self.norm = torch.ones(h, dtype=self.dtype, device=self.device) if self.pp.is_last else None
+        if not self.pp.is_first:
+            self.lm_head = None
+        elif cfg.tie_word_embeddings and sz == 1:
             self.lm_head = self.embed
         else:
-            self.lm_head = rnd(self.vocab_shard, h)
+            full = self.embed if cfg.tie_word_embeddings else self._rand(seed, 2, cfg.vocab_size, h)
+            shard = torch.zeros((self.vocab_shard, h), dtype=self.dtype, device=self.device)
+            part = full[r * self.vocab_shard:(r + 1) * self.vocab_shard]
+            shard[: part.shape[0]].copy_(part)
+            self.lm_head = shard
 
     def weight_tensors(self):
-        yield self.embed
-        yield self.norm
-        if self.lm_head is not self.embed:
+        if self.embed is not None:
+            yield self.embed
+        if self.norm is not None:
+            yield self.norm
+        if self.lm_head is not None and self.lm_head is not self.embed:
             yield self.lm_head
         for lw in self.layers:
             for s in LayerWeights.__slots__:
@@ -153,20 +198,28 @@ class TransformerModel:
         return y
 
     def forward(self, input_ids: torch.Tensor, pool: torch.Tensor, meta: BatchMeta) -> torch.Tensor:
-        """Returns the final-normed hidden states of ``meta.logits_rows`` ([num_out, H])."""
+        """Returns the final-normed hidden states of ``meta.logits_rows`` ([num_out, H]) on the
+        last pipeline stage; earlier stages hand the residual stream on and return ``None``."""
         cfg = self.cfg
-        h = F.embedding(input_ids, self.embed)
-        residual = None
+        pp = self.pp
+        if pp.is_first:
+            h = F.embedding(input_ids, self.embed)
+            residual = None
+        else:
+            shape = (input_ids.shape[0], cfg.hidden_size)
+            h = pp_recv(shape, self.dtype, self.device, pp.prev)
+            residual = pp_recv(shape, self.dtype, self.device, pp.prev)
         decode_only = meta.num_prefill_seqs == 0
         for li, lw in enumerate(self.layers):
+            gl = self.first_layer + li  # global layer index (adapters are keyed by it)
             if residual is None:
                 residual = h
                 x = ops.rms_norm(h, lw.ln1, cfg.norm_eps)
             else:
                 x = ops.rms_norm(h, lw.ln1, cfg.norm_eps, residual)
-            qkv = self._lora("qkv", li, x, F.linear(x, lw.wqkv), meta)
+            qkv = self._lora("qkv", gl, x, F.linear(x, lw.wqkv), meta)
             attn = self._attention(qkv, pool, li, meta)
-            h = self._lora("o", li, attn, F.linear(attn, lw.wo), meta)
+            h = self._lora("o", gl, attn, F.linear(attn, lw.wo), meta)
             h = tp_all_reduce(h)
             x = ops.rms_norm(h, lw.ln2, cfg.norm_eps, residual)
             if cfg.num_experts > 0:
@@ -175,12 +228,17 @@ class TransformerModel:
                 gu = F.linear(x, lw.w_gate_up)
                 h = F.linear(ops.silu_and_mul(gu), lw.w_down)
             h = tp_all_reduce(h)
+        if not pp.is_last:
+            pp_send(h, pp.next)
+            pp_send(residual, pp.next)
+            return None
         if meta.logits_rows is not None:
             h = h.index_select(0, meta.logits_rows)
             residual = residual.index_select(0, meta.logits_rows)
         return ops.rms_norm(h, self.norm, cfg.norm_eps, residual)
 
     def compute_logits(self, hidden: torch.Tensor) -> torch.Tensor:
+        """First-stage ranks only (they hold the LM head shards)."""
         logits = F.linear(hidden, self.lm_head)
         if self.tp_size > 1:
             logits = tp_all_gather_last_dim(logits)

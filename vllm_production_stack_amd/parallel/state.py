@@ -1,8 +1,12 @@
 """Process-group state for one engine replica.
 
-One process per GPU; a replica with tensor parallelism spans ``tp`` processes that
-run the same step loop in lockstep.  ``torch.distributed`` backend "nccl" is RCCL on
-ROCm (xGMI inside a node); CPU tests use gloo.
+One process per GPU.  A replica spans ``pp x tp`` processes: rank = pp_rank * tp + tp_rank,
+so a tensor-parallel group is a run of consecutive ranks (one node, xGMI) and pipeline
+stages are ``tp`` ranks apart (node to node).  All ranks run the same step loop in lockstep:
+the driver (global rank 0 of the replica) schedules and broadcasts each step's plan over a
+gloo side channel; every rank executes its shard/stage of it.
+
+``torch.distributed`` backend "nccl" is RCCL on ROCm; CPU tests use gloo.
 
 xGMI is a point-to-point mesh (7 links per GPU), so a ring all-reduce is bound by one
 link.  For the small decode-time messages ([batch, hidden] bf16, <= 2 MiB) the all-reduce
@@ -32,7 +36,49 @@ class TPGroup:
         return self.rank == 0
 
 
+@dataclass
+class PPGroup:
+    """Pipeline position of this process.  ``prev``/``next`` are global ranks of the peers that
+    hold the same tensor-parallel shard in the neighbouring stages; ``first``/``last`` are the
+    global ranks of that shard's first and last stage."""
+    rank: int = 0
+    size: int = 1
+    prev: int = -1
+    next: int = -1
+    first: int = 0
+    last: int = 0
+
+    @property
+    def is_first(self) -> bool:
+        return self.rank == 0
+
+    @property
+    def is_last(self) -> bool:
+        return self.rank == self.size - 1
+
+    def layer_range(self, num_layers: int) -> tuple[int, int]:
+        """Contiguous layers [a, b) of this stage; earlier stages take the remainder."""
+        base, extra = divmod(num_layers, self.size)
+        a = self.rank * base + min(self.rank, extra)
+        return a, a + base + (1 if self.rank < extra else 0)
+
+
+@dataclass
+class ReplicaGroup:
+    """All processes of the replica: the plan broadcast runs here (gloo)."""
+    rank: int = 0
+    size: int = 1
+    cpu_group: "dist.ProcessGroup | None" = None
+    driver: int = 0  # global rank of the driver
+
+    @property
+    def is_driver(self) -> bool:
+        return self.rank == 0
+
+
 _TP = TPGroup()
+_PP = PPGroup()
+_REPLICA = ReplicaGroup()
 # messages at or above this many bytes use reduce-scatter + all-gather
 TWO_SHOT_BYTES = 8 << 20
 
@@ -41,13 +87,41 @@ def get_tp() -> TPGroup:
     return _TP
 
 
+def get_pp() -> PPGroup:
+    return _PP
+
+
+def get_replica() -> ReplicaGroup:
+    return _REPLICA
+
+
+def set_tp(tp: TPGroup) -> None:
+    global _TP
+    _TP = tp
+
+
+def set_pp(pp: PPGroup) -> None:
+    global _PP
+    _PP = pp
+
+
+def set_replica(r: ReplicaGroup) -> None:
+    global _REPLICA
+    _REPLICA = r
+
+
+def reset_parallel_state() -> None:
+    set_tp(TPGroup())
+    set_pp(PPGroup())
+    set_replica(ReplicaGroup())
+
+
 def init_tp(tp_size: int, ranks: list[int] | None = None, backend: str | None = None) -> TPGroup:
-    """Create the tensor-parallel group from the default process group.
+    """Create a tensor-parallel group from the default process group.
 
     ``ranks`` are global ranks of this replica's group (default: all ranks)."""
-    global _TP
     if tp_size <= 1:
-        _TP = TPGroup()
+        set_tp(TPGroup())
         return _TP
     if not dist.is_initialized():
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -57,13 +131,41 @@ def init_tp(tp_size: int, ranks: list[int] | None = None, backend: str | None = 
     assert len(ranks) == tp_size, (ranks, tp_size)
     group = dist.new_group(ranks=ranks)
     cpu_group = dist.new_group(ranks=ranks, backend="gloo")
-    _TP = TPGroup(rank=ranks.index(dist.get_rank()), size=tp_size, group=group, cpu_group=cpu_group)
+    set_tp(TPGroup(rank=ranks.index(dist.get_rank()), size=tp_size, group=group, cpu_group=cpu_group))
+    set_replica(ReplicaGroup(rank=_TP.rank, size=tp_size, cpu_group=cpu_group, driver=ranks[0]))
     return _TP
 
 
-def set_tp(tp: TPGroup) -> None:
-    global _TP
-    _TP = tp
+def init_replica_parallel(tp_size: int, pp_size: int = 1) -> None:
+    """Carve the default process group into replicas of ``pp_size x tp_size`` ranks and record
+    this process's tensor-parallel group, pipeline neighbours and replica control group.
+    Every rank takes part in the creation of every group (a ``new_group`` requirement)."""
+    per = tp_size * pp_size
+    if per <= 1:
+        reset_parallel_state()
+        return
+    assert dist.is_initialized(), "init_process_group first"
+    world, me = dist.get_world_size(), dist.get_rank()
+    if world % per != 0:
+        raise ValueError(f"world size {world} is not a multiple of tp*pp = {per}")
+    for rep in range(world // per):
+        base = rep * per
+        rep_ranks = list(range(base, base + per))
+        rep_cpu = dist.new_group(ranks=rep_ranks, backend="gloo")
+        mine = me in rep_ranks
+        if mine:
+            set_replica(ReplicaGroup(rank=me - base, size=per, cpu_group=rep_cpu, driver=base))
+        for stage in range(pp_size):
+            ranks = [base + stage * tp_size + t for t in range(tp_size)]
+            grp = dist.new_group(ranks=ranks) if tp_size > 1 else None
+            cpu = dist.new_group(ranks=ranks, backend="gloo") if tp_size > 1 else None
+            if me in ranks:
+                t = ranks.index(me)
+                set_tp(TPGroup(rank=t, size=tp_size, group=grp, cpu_group=cpu))
+                set_pp(PPGroup(rank=stage, size=pp_size,
+                               prev=me - tp_size if stage > 0 else -1,
+                               next=me + tp_size if stage < pp_size - 1 else -1,
+                               first=base + t, last=base + (pp_size - 1) * tp_size + t))
 
 
 def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
@@ -85,14 +187,25 @@ def tp_all_gather_last_dim(x: torch.Tensor) -> torch.Tensor:
     tp = _TP
     if tp.size == 1:
         return x
-    x = x.contiguous()
-    out = torch.empty((tp.size, *x.shape), dtype=x.dtype, device=x.device)
-    dist.all_gather_into_tensor(out, x, group=tp.group)
-    return out.movedim(0, -2).reshape(*x.shape[:-1], x.shape[-1] * tp.size)
+    x = x.contiguous().view(-1, x.shape[-1])
+    lead = x.shape[0]
+    out = torch.empty((tp.size * lead, x.shape[1]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x, group=tp.group)  # rank-major concatenation along dim 0
+    return out.view(tp.size, lead, x.shape[1]).movedim(0, 1).reshape(lead, tp.size * x.shape[1])
+
+
+def pp_send(x: torch.Tensor, dst: int) -> None:
+    dist.send(x.contiguous(), dst=dst)
+
+
+def pp_recv(shape, dtype: torch.dtype, device: torch.device, src: int) -> torch.Tensor:
+    t = torch.empty(shape, dtype=dtype, device=device)
+    dist.recv(t, src=src)
+    return t
 
 
 def broadcast_object(obj, src: int = 0):
-    """Control-plane broadcast from the replica's driver rank over the gloo side channel."""
+    """Control-plane broadcast from the tensor-parallel group's first rank (gloo)."""
     tp = _TP
     if tp.size == 1:
         return obj
@@ -100,6 +213,26 @@ def broadcast_object(obj, src: int = 0):
     src_global = dist.get_global_rank(tp.cpu_group, src)
     dist.broadcast_object_list(box, src=src_global, group=tp.cpu_group)
     return box[0]
+
+
+def replica_broadcast(obj):
+    """Broadcast a picklable control message from the replica's driver to all its ranks."""
+    r = _REPLICA
+    if r.size == 1:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=r.driver, group=r.cpu_group)
+    return box[0]
+
+
+def replica_min_int(v: int) -> int:
+    """Minimum of an integer over the replica (e.g. the KV page count every rank can hold)."""
+    r = _REPLICA
+    if r.size == 1:
+        return v
+    t = torch.tensor([v], dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=r.cpu_group)
+    return int(t.item())
 
 
 def local_rank() -> int:
