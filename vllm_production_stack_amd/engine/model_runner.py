@@ -169,7 +169,10 @@ class ModelRunner:
             meta.dec_block_tables = self._to_dev([p + [0] * (width - len(p)) for p in pages], torch.int32)
             ctx = plan["dec_ctx"]
             meta.dec_ctx_lens = self._to_dev(ctx, torch.int32)
-            meta.dec_num_splits = ops.decode_num_splits(len(ctx), self.n_kv_local, max(ctx))
+            # same split count as the captured graph of this batch bucket: eager and graph
+            # steps then reduce in the same order and generate identical tokens
+            meta.dec_num_splits = ops.decode_num_splits(self._bucket(len(ctx)), self.n_kv_local,
+                                                        self.max_model_len)
         if plan["num_prefill"]:
             pages = plan["pre_pages"]
             width = max(len(p) for p in pages)

@@ -149,7 +149,7 @@ def decode_num_splits(num_seqs: int, n_kv: int, max_ctx: int) -> int:
     least 256 keys per split."""
     want = max(1, -(-1280 // max(1, num_seqs * n_kv)))
     by_len = max(1, max_ctx // 256)
-    return int(max(1, min(want, by_len, 64)))
+    return int(max(1, min(want, by_len, 32)))
 
 
 def paged_decode(q, out, pool, layer, block_tables, ctx_lens, n_q, n_kv, head_dim, scale,
