@@ -53,8 +53,16 @@ def main():
     ap.add_argument("--speed", type=float, default=500.0)
     ap.add_argument("--routing-logic", default="session")
     ap.add_argument("--base-port", type=int, default=19100)
+    ap.add_argument("--max-imbalance", type=float, default=None,
+                    help="fail when the per-backend share of routing decisions (read from the router "
+                         "log) deviates from the mean by more than this fraction")
     a = ap.parse_args()
     procs = []
+    router_log = None
+    if a.max_imbalance is not None:
+        import tempfile
+
+        router_log = tempfile.NamedTemporaryFile("w+", suffix="-router.log", delete=False)
     try:
         for i in range(a.engines):
             procs.append(subprocess.Popen([sys.executable, "-m", "vllm_production_stack_amd.testing.fake_engine",
@@ -65,11 +73,26 @@ def main():
                                        str(a.base_port), "--host", "127.0.0.1", "--service-discovery", "static",
                                        "--static-backends", backends, "--static-models", ",".join(["fake"] * a.engines),
                                        "--routing-logic", a.routing_logic, "--session-key", "x-user-id",
-                                       "--log-level", "warning"], cwd=ROOT))
+                                       "--log-level", "info" if router_log else "warning"], cwd=ROOT,
+                                      stdout=router_log, stderr=subprocess.STDOUT if router_log else None))
         time.sleep(2.0)
         res = asyncio.run(client(f"http://127.0.0.1:{a.base_port}", a.requests, a.concurrency, a.tokens, "x-user-id"))
         res.update(engines=a.engines, concurrency=a.concurrency, tokens_per_request=a.tokens, routing=a.routing_logic)
+        if router_log is not None:
+            import collections
+            import re
+
+            time.sleep(0.5)
+            router_log.flush()
+            with open(router_log.name, errors="replace") as f:
+                counts = collections.Counter(re.findall(r"Routing request \S+ with session id \S+ to (\S+) at", f.read()))
+            mean = sum(counts.values()) / max(1, a.engines)
+            worst = max(abs(counts.get(f"http://127.0.0.1:{a.base_port + 1 + i}", 0) - mean) / mean
+                        for i in range(a.engines)) if mean else 1.0
+            res.update(routing_decisions=dict(counts), imbalance=round(worst, 4))
         print(json.dumps(res))
+        if router_log is not None and (worst > a.max_imbalance or sum(counts.values()) < a.requests):
+            sys.exit(f"routing imbalance {worst:.2%} (limit {a.max_imbalance:.0%}) over {sum(counts.values())} decisions")
     finally:
         for p in procs:
             p.terminate()

@@ -1,0 +1,196 @@
+"""Deployment assets: the values renderer (engine CLI / env contract), the example values of every
+feature, the chart templates' structure, CRDs, and dashboard queries vs. exported metric names."""
+
+import json
+import re
+from pathlib import Path
+
+import pytest
+import yaml
+
+from vllm_production_stack_amd.deploy import render
+from vllm_production_stack_amd.deploy.stack import local_plan
+
+ROOT = Path(__file__).resolve().parents[1]
+EXAMPLES = sorted((ROOT / "deploy" / "examples").glob("values-*.yaml"))
+
+
+def _objs(path, **kw):
+    return render.render_all(render.load_values(path), **kw)
+
+
+def _kinds(objs):
+    return [(o["kind"], o["metadata"]["name"]) for o in objs]
+
+
+def _engine_container(objs, name):
+    for o in objs:
+        if o["kind"] in ("Deployment", "StatefulSet") and o["metadata"]["name"].startswith(name):
+            return o["spec"]["template"]["spec"]["containers"][0]
+    raise AssertionError(f"no workload {name} in {_kinds(objs)}")
+
+
+@pytest.mark.parametrize("path", EXAMPLES, ids=lambda p: p.stem)
+def test_every_example_renders(path):
+    objs = _objs(path)
+    assert objs, path
+    text = render.to_yaml(objs)
+    for doc in yaml.safe_load_all(text):
+        assert doc["apiVersion"] and doc["kind"] and doc["metadata"]["name"]
+    # GPU requests always go through the AMD device-plugin resource
+    for o in objs:
+        if o["kind"] in ("Deployment", "StatefulSet"):
+            for c in o["spec"]["template"]["spec"]["containers"]:
+                for sect in (c.get("resources") or {}).values():
+                    assert not any(k.startswith("nvidia.com") for k in sect)
+
+
+def test_engine_command_and_env_contract():
+    objs = _objs(ROOT / "deploy/examples/values-05-host-dram-offload.yaml")
+    c = _engine_container(objs, "vllm-llama3-deployment")
+    cmd = c["command"]
+    assert cmd[:3] == ["vpsa-engine", "serve", "meta-llama/Llama-3.1-8B-Instruct"]
+    for flag in ("--enable-prefix-caching", "--enable-chunked-prefill", "--max-model-len", "--dtype",
+                 "--swap-space", "--kv-transfer-config"):
+        assert flag in cmd
+    kvt = json.loads(cmd[cmd.index("--kv-transfer-config") + 1])
+    assert kvt == {"kv_connector": "LMCacheConnectorV1", "kv_role": "kv_both"}
+    env = {e["name"]: e.get("value") for e in c["env"]}
+    assert env["LMCACHE_LOCAL_CPU"] == "True" and env["LMCACHE_MAX_LOCAL_CPU_SIZE"] == "120"
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "HF_TOKEN" in env
+    assert c["resources"]["requests"]["amd.com/gpu"] == "1"
+    ports = {p["name"]: p["containerPort"] for p in c["ports"]}
+    assert ports == {"container-port": 8000, "zmq-port": 55555, "ucx-port": 9999}
+    router = next(o for o in objs if o["metadata"]["name"] == "vllm-deployment-router")
+    args = router["spec"]["template"]["spec"]["containers"][0]["args"]
+    assert args[args.index("--routing-logic") + 1] == "session"
+    assert args[args.index("--session-key") + 1] == "x-user-id"
+    assert args[args.index("--k8s-label-selector") + 1] == "environment=test,release=test"
+
+
+def test_disaggregated_prefill_roles_and_pools():
+    objs = _objs(ROOT / "deploy/examples/values-16-disaggregated-prefill.yaml")
+    p = _engine_container(objs, "vllm-llama-prefill-deployment")
+    d = _engine_container(objs, "vllm-llama-decode-deployment")
+    kp = json.loads(p["command"][p["command"].index("--kv-transfer-config") + 1])
+    kd = json.loads(d["command"][d["command"].index("--kv-transfer-config") + 1])
+    assert kp["kv_role"] == "kv_producer" and kd["kv_role"] == "kv_consumer"
+    envp = {e["name"]: e.get("value") for e in p["env"]}
+    assert envp["LMCACHE_NIXL_ROLE"] == "sender" and envp["LMCACHE_ENABLE_NIXL"] == "True"
+    assert envp["LMCACHE_NIXL_RECEIVER_HOST"] == "vllm-llama-decode-engine-service"
+    reps = {o["metadata"]["name"]: o["spec"]["replicas"] for o in objs if o["kind"] == "Deployment"}
+    assert reps["vllm-llama-prefill-deployment-vllm"] == 2 and reps["vllm-llama-decode-deployment-vllm"] == 6
+    plan = local_plan(render.load_values(ROOT / "deploy/examples/values-16-disaggregated-prefill.yaml"), gpus=8)
+    engines = [p for p in plan if p.role == "engine"]
+    assert len(engines) == 8
+    router = next(p for p in plan if p.role == "router")
+    assert "disaggregated_prefill" in router.argv
+
+
+def test_cache_server_and_remote_url():
+    objs = _objs(ROOT / "deploy/examples/values-06-shared-remote-cache.yaml", release="rel")
+    c = _engine_container(objs, "rel-llama3-deployment")
+    env = {e["name"]: e.get("value") for e in c["env"]}
+    assert env["LMCACHE_REMOTE_URL"] == "lm://rel-cache-server-service:81"
+    assert env["LMCACHE_REMOTE_SERDE"] == "cachegen"
+    cs = next(o for o in objs if o["metadata"]["name"] == "rel-deployment-cache-server")
+    cmd = cs["spec"]["template"]["spec"]["containers"][0]["command"]
+    assert cmd[:3] == ["vpsa-cache-server", "0.0.0.0", "8080"] and "--max-bytes" in cmd
+
+
+def test_multinode_layout():
+    objs = _objs(ROOT / "deploy/examples/values-15-pipeline-parallel.yaml")
+    sts = next(o for o in objs if o["kind"] == "StatefulSet")
+    assert sts["spec"]["replicas"] == 2  # pp2 x tp8 over 8-GPU nodes
+    cmd = sts["spec"]["template"]["spec"]["containers"][0]["command"]
+    assert cmd[cmd.index("--pipeline-parallel-size") + 1] == "2"
+    assert cmd[cmd.index("--tensor-parallel-size") + 1] == "8"
+    assert any(o["kind"] == "Service" and o["spec"].get("clusterIP") == "None" for o in objs)
+
+
+def test_secrets_are_collected_and_referenced():
+    objs = _objs(ROOT / "deploy/examples/values-11-secure.yaml")
+    sec = next(o for o in objs if o["kind"] == "Secret")
+    assert sec["stringData"]["vllmApiKey"] == "change-me" and "hf_token_llama3" in sec["stringData"]
+    c = _engine_container(objs, "vllm-llama3-deployment")
+    key = next(e for e in c["env"] if e["name"] == "VLLM_API_KEY")
+    assert key["valueFrom"]["secretKeyRef"] == {"name": "vllm-secrets", "key": "vllmApiKey"}
+
+
+def test_missing_required_value_is_reported():
+    vals = render.load_values(overrides={"servingEngineSpec": {"modelSpec": [{"name": "m", "modelURL": "x"}]}})
+    with pytest.raises(render.ValuesError, match="requestMemory"):
+        render.render_all(vals)
+
+
+# --------------------------------------------------------------------------- chart structure
+_OPEN = re.compile(r"{{-?\s*(if|range|with|define)\b")
+_END = re.compile(r"{{-?\s*end\s*-?}}")
+
+
+@pytest.mark.parametrize("path", sorted((ROOT / "deploy/helm/templates").glob("*")), ids=lambda p: p.name)
+def test_chart_template_blocks_balance(path):
+    text = path.read_text()
+    # strip template comments (they may mention keywords)
+    text = re.sub(r"{{-?\s*/\*.*?\*/\s*-?}}", "", text, flags=re.S)
+    assert len(_OPEN.findall(text)) == len(_END.findall(text)), path.name
+    # every action closes on its own line (text after it may contain literal braces, e.g. JSON)
+    assert "{{" not in re.sub(r"{{.*?}}", "", text)
+
+
+def test_chart_covers_what_the_renderer_emits():
+    """Every object kind the renderer can emit has a chart template producing that kind."""
+    chart = "\n".join(p.read_text() for p in (ROOT / "deploy/helm/templates").glob("*.yaml"))
+    kinds = set()
+    for path in EXAMPLES:
+        kinds |= {o["kind"] for o in _objs(path)}
+    vals = render.load_values(overrides={
+        "servingEngineSpec": {"configs": {"A": "b"}, "maxUnavailablePodDisruptionBudget": "1",
+                              "modelSpec": [{"name": "m", "modelURL": "x", "requestCPU": 1, "requestMemory": "1Gi"}]},
+        "routerSpec": {"autoscaling": {"enabled": True}, "ingress": {"enabled": True}},
+        "sharedPvcStorage": {"hostPath": "/x"}})
+    kinds |= {o["kind"] for o in render.render_all(vals)}
+    for k in kinds:
+        assert re.search(rf"^kind: {k}\b", chart, flags=re.M) or k == "HTTPRoute", k
+    assert "HTTPRoute" in chart
+
+
+def test_crds_and_samples_agree():
+    crd_dir = ROOT / "deploy/operator/crds"
+    kinds = {}
+    for p in crd_dir.glob("*.yaml"):
+        crd = yaml.safe_load(p.read_text())
+        v = crd["spec"]["versions"][0]
+        kinds[crd["spec"]["names"]["kind"]] = v["schema"]["openAPIV3Schema"]["properties"]["spec"]["properties"]
+    assert set(kinds) == {"VLLMRuntime", "VLLMRouter", "CacheServer", "LoraAdapter"}
+    for p in (ROOT / "deploy/operator/samples").glob("*.yaml"):
+        cr = yaml.safe_load(p.read_text())
+        assert cr["apiVersion"] == "production-stack.vllm.ai/v1alpha1"
+        unknown = set(cr["spec"]) - set(kinds[cr["kind"]])
+        assert not unknown, (p.name, unknown)
+    router_enum = kinds["VLLMRouter"]["routingLogic"]["enum"]
+    assert set(router_enum) == {"roundrobin", "session", "prefixaware", "kvaware", "disaggregated_prefill"}
+
+
+def test_dashboards_chart_exported_series():
+    src = (ROOT / "vllm_production_stack_amd/engine/metrics.py").read_text()
+    src += (ROOT / "vllm_production_stack_amd/router/metrics.py").read_text()
+    dash = json.loads((ROOT / "deploy/observability/serving-dashboard.json").read_text())
+    cm = yaml.safe_load((ROOT / "deploy/observability/kv-tier-dashboard-cm.yaml").read_text())
+    dash2 = json.loads(cm["data"]["kv-tier-dashboard.json"])
+    names = set()
+    for d in (dash, dash2):
+        for p in d["panels"]:
+            for t in p.get("targets", []):
+                names |= set(re.findall(r"(?:vllm|lmcache):[a-z_]+|router_[a-z_]+", t["expr"]))
+    assert len(names) > 20
+    for n in names:
+        base = re.sub(r"_(bucket|total)$", "", n)
+        assert base in src, f"dashboard charts {n}, which nothing exports"
+
+
+def test_all_plain_yaml_parses():
+    for p in list((ROOT / "deploy").rglob("*.yaml")):
+        if "helm/templates" in str(p):
+            continue
+        list(yaml.safe_load_all(p.read_text()))
