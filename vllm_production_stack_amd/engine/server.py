@@ -196,9 +196,13 @@ class EngineServer:
 
     async def debug_stats(self, request):
         e = self.engine
-        return web.json_response({"prof": e.prof, "preemptions": e.scheduler.num_preemptions,
-                                  "prefix_hits": e.bm.hits, "prefix_queries": e.bm.queries,
-                                  "free_pages": e.bm.num_free(), "graphs": sorted(e.runner._graphs)})
+        out = {"prof": e.prof, "preemptions": e.scheduler.num_preemptions,
+               "prefix_hits": e.bm.hits, "prefix_queries": e.bm.queries,
+               "free_pages": e.bm.num_free(), "graphs": sorted(e.runner._graphs),
+               "page_bytes": e.runner.page_bytes}
+        if e.connector is not None:
+            out["pd_push"] = e.connector.pd_stats
+        return web.json_response(out)
 
     # ------------------------------------------------------------------ P->D KV receive side
     def _kv_receiver(self):

@@ -216,6 +216,12 @@ class KVConnector:
             self._report({"instance_id": self.instance_id, "evict": [h]})
 
     # ------------------------------------------------------------------ disaggregated prefill
+    @property
+    def pd_stats(self) -> dict:
+        if not hasattr(self, "_pd_stats"):
+            self._pd_stats = {"pushes": 0, "pages": 0, "seconds": 0.0, "by_mode": {}}
+        return self._pd_stats
+
     def on_request_finished(self, req) -> None:
         kvp = req.kv_transfer_params or {}
         if not kvp.get("do_remote_decode") or self.role == "kv_consumer":
@@ -231,6 +237,11 @@ class KVConnector:
         t0 = time.time()
         try:
             mode = push_request_pages(self.engine, target, req.hashes[:n_full], req.pages[:n_full])
+            st = self.pd_stats
+            st["pushes"] += 1
+            st["pages"] += n_full
+            st["seconds"] += time.time() - t0
+            st["by_mode"][mode] = st["by_mode"].get(mode, 0) + 1
             log.info("pushed %d KV pages of %s to %s via %s in %.1f ms", n_full, req.request_id,
                      target, mode, (time.time() - t0) * 1e3)
         except Exception as e:
