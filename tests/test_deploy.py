@@ -194,3 +194,41 @@ def test_all_plain_yaml_parses():
         if "helm/templates" in str(p):
             continue
         list(yaml.safe_load_all(p.read_text()))
+
+
+def _validate(schema, value, path="values"):
+    """Tiny JSON-schema subset checker (type / enum / required / properties / items / oneOf)."""
+    if "oneOf" in schema:
+        errs = []
+        for s in schema["oneOf"]:
+            try:
+                _validate(s, value, path)
+                return
+            except AssertionError as e:
+                errs.append(str(e))
+        raise AssertionError(f"{path}: no oneOf branch matches ({errs})")
+    if "enum" in schema:
+        assert value in schema["enum"], f"{path}: {value!r} not in {schema['enum']}"
+    t = schema.get("type")
+    if t:
+        names = {"string": str, "integer": int, "number": (int, float), "boolean": bool, "object": dict, "array": list}
+        ts = t if isinstance(t, list) else [t]
+        ok = any(isinstance(value, names[x]) and not (x in ("integer", "number") and isinstance(value, bool)) for x in ts)
+        assert ok, f"{path}: {type(value).__name__} is not {t}"
+    if isinstance(value, dict):
+        for r in schema.get("required", []):
+            assert r in value, f"{path}: missing {r}"
+        props = schema.get("properties")
+        if props is not None and not schema.get("additionalProperties"):
+            for k, v in value.items():
+                assert k in props, f"{path}: unknown key {k}"
+                _validate(props[k], v, f"{path}.{k}")
+    if isinstance(value, list) and "items" in schema:
+        for i, v in enumerate(value):
+            _validate(schema["items"], v, f"{path}[{i}]")
+
+
+@pytest.mark.parametrize("path", EXAMPLES + [ROOT / "deploy/helm/values.yaml"], ids=lambda p: p.stem)
+def test_values_match_schema(path):
+    schema = json.loads((ROOT / "deploy/helm/values.schema.json").read_text())
+    _validate(schema, yaml.safe_load(path.read_text()) or {})
