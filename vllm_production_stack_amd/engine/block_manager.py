@@ -10,6 +10,8 @@ a lower tier (pinned host DRAM) can keep the content.
 from __future__ import annotations
 
 import struct
+import sys
+from array import array
 from collections import OrderedDict, deque
 from typing import Callable, Iterable
 
@@ -24,13 +26,20 @@ def chain_hashes(token_ids: list[int], salt: bytes = b"", prev: int = 0, start_p
     out = []
     h = prev
     n_full = len(token_ids) // page
-    for p in range(start_page, n_full):
-        chunk = token_ids[p * page:(p + 1) * page]
-        x = xxhash.xxh64()
-        x.update(struct.pack("<Q", h))
+    if n_full <= start_page:
+        return out
+    # one packing pass for all pages (same bytes as struct.pack("<{page}i") per page)
+    a = array("i", token_ids[start_page * page:n_full * page])
+    if sys.byteorder != "little":  # pragma: no cover - hashes are defined on little-endian words
+        a.byteswap()
+    mv = memoryview(a.tobytes())
+    step = 4 * page
+    pack_q = struct.Struct("<Q").pack
+    for i in range(n_full - start_page):
+        x = xxhash.xxh64(pack_q(h))
         if salt:
             x.update(salt)
-        x.update(struct.pack(f"<{page}i", *chunk))
+        x.update(mv[i * step:(i + 1) * step])
         h = x.intdigest()
         out.append(h)
     return out

@@ -159,6 +159,9 @@ class LLMEngine:
         pr["t_schedule"] += t_b - t_a
         pr["t_execute"] += t_c - t_b
         pr["t_post"] += time.perf_counter() - t_c
+        pr["t_plan"] = self.runner.t_plan
+        pr["t_materialize"] = self.runner.t_materialize
+        pr["t_launch"] = self.runner.t_launch
         return outputs
 
     def _stop_reason(self, req: Request, tok: int) -> str | None:

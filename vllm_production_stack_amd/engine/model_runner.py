@@ -20,6 +20,7 @@ from __future__ import annotations
 import logging
 import time
 
+import numpy as np
 import torch
 
 from .. import ops
@@ -72,6 +73,8 @@ class ModelRunner:
         self._pin = device.type == "cuda"
         self.sleeping = False
         self._sleep_stash: list[tuple[torch.Tensor, torch.Tensor]] = []
+        # host-side seconds of eager steps: plan lists, device tensors, kernel launches
+        self.t_plan = self.t_materialize = self.t_launch = 0.0
 
     # ------------------------------------------------------------------ memory plan
     def _plan_pages(self) -> int:
@@ -135,8 +138,10 @@ class ModelRunner:
             else:
                 ids.extend(r.all_ids[s.start:s.start + s.n])
             pos.extend(range(s.start, s.start + s.n))
-            pages = r.pages
-            slots.extend(pages[t // PAGE] * PAGE + t % PAGE for t in range(s.start, s.start + s.n))
+            t = np.arange(s.start, s.start + s.n, dtype=np.int64)
+            first = s.start // PAGE
+            pg = np.asarray(r.pages[first:(s.start + s.n - 1) // PAGE + 1], dtype=np.int64)
+            slots.extend((pg[t // PAGE - first] * PAGE + t % PAGE).tolist())
             row += s.n
             if s.samples:
                 logits_rows.append(row - 1)
@@ -196,8 +201,12 @@ class ModelRunner:
     def _run_plan(self, plan: dict):
         """Every rank of the replica: run this rank's part of the step.  Returns the logits
         ([num_out, vocab]) on first-stage ranks when the step samples, else ``None``."""
+        t0 = time.perf_counter()
         ids, meta = self._materialize(plan)
+        t1 = time.perf_counter()
         hidden = self.model.forward(ids, self.pool, meta)
+        self.t_materialize += t1 - t0
+        self.t_launch += time.perf_counter() - t1
         n_out = len(plan["logits_rows"])
         if n_out == 0:
             return None, None
@@ -231,7 +240,9 @@ class ModelRunner:
                 and all(s.samples for s in out.decodes)
                 and len(out.decodes) <= _GRAPH_BUCKETS[-1]):
             return self._execute_decode_graph(out.decodes)
+        t0 = time.perf_counter()
         plan, sample_seqs = self._plan(out.decodes, out.prefills)
+        self.t_plan += time.perf_counter() - t0
         if self.distributed:
             replica_broadcast(("step", plan))
         hidden, logits = self._run_plan(plan)

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import json
 import re
+from collections import OrderedDict
 from pathlib import Path
 
 import xxhash
@@ -89,6 +90,12 @@ class SyntheticTokenizer(BaseTokenizer):
         self._space = max(1, vocab_size - self._base)
         self._words: dict[int, str] = {}
         self._memo: dict[str, int] = {}
+        # per-message id cache for chat prompts: a conversation re-sends its whole history every
+        # turn, and word-level tokenisation of space-joined segments is the concatenation of the
+        # segments' ids, so only the new messages of a turn are tokenised
+        self._seg_cache: "OrderedDict[tuple, list[int]]" = OrderedDict()
+        self._seg_cached_ids = 0
+        self._seg_cache_limit = 8_000_000  # ids
 
     def _word_id(self, w: str) -> int:
         if w in self._special:
@@ -122,6 +129,39 @@ class SyntheticTokenizer(BaseTokenizer):
         if add_special_tokens and (not ids or ids[0] != self.bos_token_id):
             ids.insert(0, self.bos_token_id)
         return ids
+
+    def _segment_ids(self, seg: str) -> list[int]:
+        if len(seg) < 2048:
+            return self.encode(seg, add_special_tokens=False)
+        key = (len(seg), xxhash.xxh64_intdigest(seg))
+        cache = self._seg_cache
+        ids = cache.get(key)
+        if ids is not None:
+            cache.move_to_end(key)
+            return ids
+        ids = self.encode(seg, add_special_tokens=False)
+        cache[key] = ids
+        self._seg_cached_ids += len(ids)
+        while self._seg_cached_ids > self._seg_cache_limit and len(cache) > 1:
+            _, old = cache.popitem(last=False)
+            self._seg_cached_ids -= len(old)
+        return ids
+
+    def encode_chat(self, messages: list[dict], add_generation_prompt: bool = True,
+                    tools: list | None = None) -> list[int]:
+        if self.chat_template or tools:
+            return super().encode_chat(messages, add_generation_prompt, tools)
+        # same text as render_chat's built-in template, tokenised segment by segment
+        out = [self.bos_token_id]
+        for m in messages:
+            text = self._content_text(m.get("content"))
+            if m.get("tool_calls"):
+                text += " " + json.dumps(m["tool_calls"])
+            out.extend(self._segment_ids(
+                f"<|start_header_id|> {m.get('role', 'user')} <|end_header_id|> {text} <|eot_id|>"))
+        if add_generation_prompt:
+            out.extend(self.encode("<|start_header_id|> assistant <|end_header_id|>", add_special_tokens=False))
+        return out
 
     def decode(self, ids: list[int], skip_special_tokens: bool = True) -> str:
         words = []
