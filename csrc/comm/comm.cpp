@@ -70,9 +70,11 @@ API int comm_rccl_unique_id(void* out) {
   return 0;
 }
 
-API void* comm_rccl_init(const void* id_bytes, int nranks, int rank) {
+// Blocks until all `nranks` processes have called it with the same id (run it on its own thread).
+API void* comm_rccl_init(const void* id_bytes, int nranks, int rank, int device) {
   ncclUniqueId id;
   memcpy(&id, id_bytes, sizeof(id));
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
   ncclComm_t c = nullptr;
   if (ncclCommInitRank(&c, nranks, id, rank) != ncclSuccess) return nullptr;
   return c;

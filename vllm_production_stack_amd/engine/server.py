@@ -91,6 +91,8 @@ class EngineServer:
         r.add_post("/kv/reserve", self.kv_reserve)
         r.add_post("/kv/push", self.kv_push)
         r.add_post("/kv/commit", self.kv_commit)
+        r.add_post("/kv/rccl_init", self.kv_rccl_init)
+        r.add_post("/kv/rccl_recv", self.kv_rccl_recv)
         self._receiver = None
 
     # ------------------------------------------------------------------ middleware
@@ -227,6 +229,26 @@ class EngineServer:
         meta = json.loads(raw[4:4 + n])
         rcv = self._kv_receiver()
         res = await self.ae.call(lambda: rcv.push(meta["pages"], raw[4 + n:]))
+        return web.json_response(res)
+
+    async def kv_rccl_init(self, request):
+        d = await request.json()
+        rcv = self._kv_receiver()
+        try:
+            # joins the communicator on a worker thread: the engine loop keeps serving while the
+            # prefill replica's side of the rendezvous arrives
+            res = await asyncio.get_running_loop().run_in_executor(None, rcv.rccl_init, d["id"])
+        except (ValueError, RuntimeError) as e:
+            return _err(409, str(e), "KVTransferError")
+        return web.json_response(res)
+
+    async def kv_rccl_recv(self, request):
+        d = await request.json()
+        rcv = self._kv_receiver()
+        try:
+            res = await self.ae.call(lambda: rcv.rccl_recv(d["comm"], d["pages"], int(d["page_bytes"])))
+        except (KeyError, RuntimeError) as e:
+            return _err(409, str(e), "KVTransferError")
         return web.json_response(res)
 
     async def kv_commit(self, request):

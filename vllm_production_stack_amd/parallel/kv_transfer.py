@@ -6,8 +6,10 @@ Protocol (control plane = the replicas' own HTTP ports, data plane chosen per pa
   2. producer  moves the page bytes:
         ipc   the decode pool is mapped through a hipIpc handle and written with
               hipMemcpyAsync on a side stream (SDMA over the direct xGMI link),
-        rccl  torch.distributed batched isend/irecv (RCCL send/recv) when both replicas
-              are ranks of one process group,
+        rccl  ncclSend / ncclRecv of whole pages on side streams, over a two-rank RCCL
+              communicator created per (prefill, decode) pair (the unique id travels over the
+              control plane); for GPUs that cannot exchange IPC handles (other node, other
+              container namespace).  Opt-in: VPSA_PD_TRANSPORT=rccl,
         tcp   POST <decode>/kv/push with the raw page bytes (any host, CPU tests);
   3. producer  POST <decode>/kv/commit {hashes, pages} -> pages are published in the decode
      replica's prefix cache; the decode request then finds its prompt resident.
@@ -31,6 +33,26 @@ from .. import _native
 log = logging.getLogger("vpsa.kvxfer")
 _comm = None
 _peer_maps: dict[str, tuple[int, int]] = {}  # target url -> (mapped base ptr, page_bytes)
+_rccl_peers: dict[str, tuple[int, str]] = {}  # target url -> (communicator, key on the decode side)
+
+
+def host_identity() -> str:
+    """Same string for two processes iff they can exchange hipIpc handles by construction:
+    one kernel instance (boot id) and one hostname."""
+    import socket
+
+    try:
+        with open("/proc/sys/kernel/random/boot_id") as f:
+            boot = f.read().strip()
+    except OSError:
+        boot = ""
+    return f"{socket.gethostname()}/{boot}"
+
+
+def transport_preference() -> str:
+    import os
+
+    return os.environ.get("VPSA_PD_TRANSPORT", "auto").lower()
 
 
 def comm():
@@ -45,6 +67,15 @@ def comm():
         lib.comm_ipc_close.argtypes = [c_void_p]
         lib.comm_push_pages.restype = c_int
         lib.comm_push_pages.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p]
+        lib.comm_rccl_unique_id_size.restype = c_int
+        lib.comm_rccl_unique_id.restype = c_int
+        lib.comm_rccl_unique_id.argtypes = [c_void_p]
+        lib.comm_rccl_init.restype = c_void_p
+        lib.comm_rccl_init.argtypes = [c_void_p, c_int, c_int, c_int]
+        lib.comm_rccl_destroy.argtypes = [c_void_p]
+        for fn in (lib.comm_rccl_send_pages, lib.comm_rccl_recv_pages):
+            fn.restype = c_int
+            fn.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_void_p]
         _comm = lib
     return _comm
 
@@ -94,12 +125,20 @@ def push_request_pages(engine, target: str, hashes: list[int], pages: list[int])
     idx = {h: i for i, h in enumerate(hashes)}
     src = [pages[idx[h]] for h in missing]
     mode = "tcp"
-    if pool.is_cuda and res.get("ipc_handle") and res.get("same_host"):
+    pref = transport_preference()
+    same_host = res.get("host_id") == host_identity()
+    if pool.is_cuda and pref in ("auto", "ipc") and res.get("ipc_handle") and same_host:
         try:
             _push_ipc(pool, target, res["ipc_handle"], res.get("pool_offset", 0), page_bytes, src, dst_pages)
             mode = "ipc"
         except Exception as e:
-            log.warning("ipc push failed (%s); falling back to tcp", e)
+            log.warning("ipc push failed (%s); falling back", e)
+    if mode == "tcp" and pool.is_cuda and pref == "rccl" and res.get("gpu"):
+        try:
+            _push_rccl(pool, target, page_bytes, src, dst_pages)
+            mode = "rccl"
+        except Exception as e:
+            log.warning("rccl push failed (%s); falling back to tcp", e)
     if mode == "tcp":
         chunk = 8
         for i in range(0, len(src), chunk):
@@ -138,6 +177,47 @@ def _push_ipc(pool, target, handle_hex, pool_offset, page_bytes, src_pages, dst_
     stream.synchronize()
 
 
+def _push_rccl(pool, target, page_bytes, src_pages, dst_pages) -> None:
+    """ncclSend the pages; the decode replica posts the matching ncclRecv first."""
+    import threading
+
+    lib = comm()
+    ent = _rccl_peers.get(target)
+    if ent is None:
+        n = lib.comm_rccl_unique_id_size()
+        uid = ctypes.create_string_buffer(n)
+        if lib.comm_rccl_unique_id(uid) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        key = uid.raw.hex()
+        err: list[Exception] = []
+
+        def join_remote():
+            try:
+                _post(target + "/kv/rccl_init", {"id": key}, timeout=120.0)
+            except Exception as e:  # surfaced after our own init returns or times out
+                err.append(e)
+
+        th = threading.Thread(target=join_remote, daemon=True)
+        th.start()
+        c = lib.comm_rccl_init(uid, 2, 0, pool.device.index or 0)
+        th.join()
+        if err or not c:
+            raise RuntimeError(f"RCCL communicator setup failed: {err[0] if err else 'ncclCommInitRank'}")
+        ent = (c, key)
+        _rccl_peers[target] = ent
+    c, key = ent
+    n = len(src_pages)
+    _post(target + "/kv/rccl_recv", {"comm": key, "pages": dst_pages, "page_bytes": page_bytes})
+    sp = (ctypes.c_int64 * n)(*src_pages)
+    stream = torch.cuda.Stream(device=pool.device)
+    stream.wait_stream(torch.cuda.current_stream())
+    rc = lib.comm_rccl_send_pages(c_void_p(c), c_void_p(pool.data_ptr()), page_bytes, sp, n, 1,
+                                  c_void_p(stream.cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"ncclSend failed ({rc})")
+    stream.synchronize()
+
+
 # ------------------------------------------------------------------ decode side (engine thread)
 class KVReceiver:
     """Runs inside the decode replica; methods are invoked on the engine thread."""
@@ -146,6 +226,8 @@ class KVReceiver:
         self.engine = engine
         self.reserved: dict[int, int] = {}  # hash -> page reserved for an in-flight transfer
         self._handle = None
+        self._rccl: dict[str, int] = {}  # unique id (hex) -> communicator with one prefill replica
+        self._rccl_stream = None
 
     def reserve(self, hashes: list[int], page_bytes: int) -> dict:
         bm = self.engine.bm
@@ -161,11 +243,37 @@ class KVReceiver:
             self.reserved[h] = p
         if self._handle is None:
             self._handle = export_ipc_handle(pool) or ""
-        import socket
-
         return {"pages": pages, "missing": missing, "ipc_handle": self._handle or None,
                 "pool_offset": pool.data_ptr() - pool.untyped_storage().data_ptr() if pool.is_cuda else 0,
-                "same_host": True, "host": socket.gethostname()}
+                "host_id": host_identity(), "gpu": bool(pool.is_cuda)}
+
+    def rccl_init(self, key: str) -> dict:
+        """Join the two-rank communicator a prefill replica is creating (blocks until it joined)."""
+        pool = self.engine.runner.pool
+        if not pool.is_cuda:
+            raise ValueError("RCCL transport needs a GPU replica")
+        if key not in self._rccl:
+            uid = bytes.fromhex(key)
+            c = comm().comm_rccl_init(ctypes.create_string_buffer(uid, len(uid)), 2, 1, pool.device.index or 0)
+            if not c:
+                raise RuntimeError("ncclCommInitRank failed")
+            self._rccl[key] = c
+        return {"ok": True}
+
+    def rccl_recv(self, key: str, pages: list[int], page_bytes: int) -> dict:
+        """Post ncclRecv for ``pages`` on the receive stream; ``commit`` waits for completion."""
+        pool = self.engine.runner.pool
+        c = self._rccl[key]
+        if self._rccl_stream is None:
+            self._rccl_stream = torch.cuda.Stream(device=pool.device)
+        self._rccl_stream.wait_stream(torch.cuda.current_stream())
+        n = len(pages)
+        dp = (ctypes.c_int64 * n)(*pages)
+        rc = comm().comm_rccl_recv_pages(c_void_p(c), c_void_p(pool.data_ptr()), page_bytes, dp, n, 0,
+                                         c_void_p(self._rccl_stream.cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"ncclRecv failed ({rc})")
+        return {"ok": True}
 
     def push(self, pages: list[int], raw: bytes) -> dict:
         pool = self.engine.runner.pool
