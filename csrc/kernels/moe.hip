@@ -161,3 +161,130 @@ VPSA_EXPORT int vpsa_moe_combine(const void* y, const float* weights, const int*
                      weights, pos, (uint16_t*)out, hidden, topk);
   return 0;
 }
+
+// ---------------------------------------------------------------------------------
+// Small-batch expert MLP (decode): only the experts a token was routed to are read.
+// Pair p = t * topk + k uses expert e = ids[p] on token t.  Both kernels are weight-streaming
+// GEMVs: a wave owns ROWS output rows, every lane walks the reduction dimension in 16-byte
+// chunks (ROWS (x2 for gate/up) independent 16-byte loads in flight per step), partial sums
+// are combined with wave shuffles.  No host sync and no data-dependent launch shape, so the
+// step stays capturable in a HIP graph.
+//   gate_up: act[p, n] = silu(W13[e][n, :] . x[t]) * (W13[e][I + n, :] . x[t])     n < I
+//   down:    y[p, h]   = W2[e][h, :] . act[p, :]                                    h < H
+// grid = (ceil(rows / (4 * ROWS)), pairs), block = 256.
+// ---------------------------------------------------------------------------------
+#define GEMV_ROWS 4
+
+__device__ __forceinline__ float dot8(u32x4 w, u32x4 a) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s += bf16lo(w[j]) * bf16lo(a[j]);
+    s += bf16hi(w[j]) * bf16hi(a[j]);
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(256) void moe_gemv_gate_up_kernel(
+    const uint16_t* __restrict__ x, const uint16_t* __restrict__ w13, const int* __restrict__ ids,
+    uint16_t* __restrict__ act, int hidden, int inter, int topk) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int p = blockIdx.y;
+  const int t = p / topk;
+  const int e = ids[p];
+  const int n0 = (blockIdx.x * 4 + wave) * GEMV_ROWS;
+  if (n0 >= inter) return;
+  const int chunks = hidden >> 3;
+  const u32x4* xv = reinterpret_cast<const u32x4*>(x + (long)t * hidden);
+  const uint16_t* wbase = w13 + (long)e * 2 * inter * hidden;
+  float g[GEMV_ROWS], u[GEMV_ROWS];
+#pragma unroll
+  for (int r = 0; r < GEMV_ROWS; ++r) g[r] = u[r] = 0.f;
+  for (int c = lane; c < chunks; c += 64) {
+    const u32x4 a = xv[c];
+    u32x4 wg[GEMV_ROWS], wu[GEMV_ROWS];
+#pragma unroll
+    for (int r = 0; r < GEMV_ROWS; ++r) {
+      const int n = n0 + r < inter ? n0 + r : inter - 1;
+      wg[r] = reinterpret_cast<const u32x4*>(wbase + (long)n * hidden)[c];
+      wu[r] = reinterpret_cast<const u32x4*>(wbase + (long)(inter + n) * hidden)[c];
+    }
+#pragma unroll
+    for (int r = 0; r < GEMV_ROWS; ++r) {
+      g[r] += dot8(wg[r], a);
+      u[r] += dot8(wu[r], a);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < GEMV_ROWS; ++r) {
+    g[r] = wave_reduce_sum(g[r]);
+    u[r] = wave_reduce_sum(u[r]);
+  }
+  if (lane < GEMV_ROWS && n0 + lane < inter) {
+    float gv = 0.f, uv = 0.f;
+#pragma unroll
+    for (int r = 0; r < GEMV_ROWS; ++r)
+      if (r == lane) { gv = g[r]; uv = u[r]; }
+    // the library path rounds gate/up to bf16 before the activation: do the same
+    gv = bf16_bits_to_f32(__builtin_bit_cast(uint16_t, (bf16_t)gv));
+    uv = bf16_bits_to_f32(__builtin_bit_cast(uint16_t, (bf16_t)uv));
+    const float s = gv / (1.f + __expf(-gv)) * uv;
+    act[(long)p * inter + n0 + lane] = __builtin_bit_cast(uint16_t, (bf16_t)s);
+  }
+}
+
+__global__ __launch_bounds__(256) void moe_gemv_down_kernel(
+    const uint16_t* __restrict__ act, const uint16_t* __restrict__ w2, const int* __restrict__ ids,
+    uint16_t* __restrict__ y, int hidden, int inter) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int p = blockIdx.y;
+  const int e = ids[p];
+  const int h0 = (blockIdx.x * 4 + wave) * GEMV_ROWS;
+  if (h0 >= hidden) return;
+  const int chunks = inter >> 3;
+  const u32x4* av = reinterpret_cast<const u32x4*>(act + (long)p * inter);
+  const uint16_t* wbase = w2 + (long)e * hidden * inter;
+  float acc[GEMV_ROWS];
+#pragma unroll
+  for (int r = 0; r < GEMV_ROWS; ++r) acc[r] = 0.f;
+  for (int c = lane; c < chunks; c += 64) {
+    const u32x4 a = av[c];
+    u32x4 w[GEMV_ROWS];
+#pragma unroll
+    for (int r = 0; r < GEMV_ROWS; ++r) {
+      const int h = h0 + r < hidden ? h0 + r : hidden - 1;
+      w[r] = reinterpret_cast<const u32x4*>(wbase + (long)h * inter)[c];
+    }
+#pragma unroll
+    for (int r = 0; r < GEMV_ROWS; ++r) acc[r] += dot8(w[r], a);
+  }
+#pragma unroll
+  for (int r = 0; r < GEMV_ROWS; ++r) acc[r] = wave_reduce_sum(acc[r]);
+  if (lane < GEMV_ROWS && h0 + lane < hidden) {
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < GEMV_ROWS; ++r)
+      if (r == lane) v = acc[r];
+    y[(long)p * hidden + h0 + lane] = __builtin_bit_cast(uint16_t, (bf16_t)v);
+  }
+}
+
+// x [tokens, hidden], w13 [E, 2*inter, hidden], w2 [E, hidden, inter], ids [tokens*topk]
+// act [tokens*topk, inter] and y [tokens*topk, hidden] are caller-provided workspaces.
+VPSA_EXPORT int vpsa_moe_gemv(const void* x, const void* w13, const void* w2, const int* ids,
+                              void* act, void* y, int tokens, int topk, int hidden, int inter,
+                              hipStream_t stream) {
+  const int pairs = tokens * topk;
+  if (pairs <= 0) return 0;
+  if (hidden % 8 != 0 || inter % 8 != 0) return -1;
+  const int per_block = 4 * GEMV_ROWS;
+  hipLaunchKernelGGL(moe_gemv_gate_up_kernel, dim3((inter + per_block - 1) / per_block, pairs),
+                     dim3(256), 0, stream, (const uint16_t*)x, (const uint16_t*)w13, ids,
+                     (uint16_t*)act, hidden, inter, topk);
+  hipLaunchKernelGGL(moe_gemv_down_kernel, dim3((hidden + per_block - 1) / per_block, pairs),
+                     dim3(256), 0, stream, (const uint16_t*)act, (const uint16_t*)w2, ids,
+                     (uint16_t*)y, hidden, inter);
+  return 0;
+}

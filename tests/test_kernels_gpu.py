@@ -229,3 +229,17 @@ def test_moe_routing():
     out = ops.moe_combine(xs, w, pos, t)
     exp = (x.float() * w.sum(1, keepdim=True)).to(BF)
     torch.testing.assert_close(out.float(), exp.float(), atol=3e-2, rtol=3e-2)
+
+
+@pytest.mark.parametrize("t,hidden,inter", [(1, 4096, 14336), (5, 256, 264), (16, 512, 1024)])
+def test_moe_small_batch_experts(t, hidden, inter):
+    torch.manual_seed(18)
+    e, k = 8, 2
+    x = torch.randn(t, hidden, device=DEV).to(BF)
+    w13 = (torch.randn(e, 2 * inter, hidden, device=DEV) * 0.03).to(BF)
+    w2 = (torch.randn(e, hidden, inter, device=DEV) * 0.03).to(BF)
+    logits = torch.randn(t, e, device=DEV).to(BF)
+    w, ids = ops.moe_topk_softmax(logits, k)
+    out = ops.moe_experts_small_batch(x, w13, w2, ids, w)
+    exp = ref.moe_experts(x, w13, w2, ids, w)
+    torch.testing.assert_close(out.float(), exp.float(), atol=3e-2, rtol=3e-2)

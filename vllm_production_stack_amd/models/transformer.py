@@ -172,6 +172,9 @@ class TransformerModel:
         e, k = cfg.num_experts, cfg.num_experts_per_tok
         logits = F.linear(x, lw.router)
         w, ids = ops.moe_topk_softmax(logits, k)
+        if decode_only and t <= 16 and x.is_cuda:
+            # A handful of tokens: stream only the routed experts' weights (GEMV kernels).
+            return ops.moe_experts_small_batch(x, lw.w13, lw.w2, ids, w)
         if decode_only or t <= 16:
             # Small batches: every expert's weights are streamed anyway, so run all experts
             # on all rows (no host sync: HIP-graph capturable) and mix with the routing matrix.

@@ -29,6 +29,7 @@ def _kernels():
             "vpsa_paged_prefill", "vpsa_set_prefill_variant", "vpsa_paged_decode", "vpsa_kv_gather_pages",
             "vpsa_kv_scatter_pages", "vpsa_cachegen_encode", "vpsa_cachegen_decode",
             "vpsa_moe_topk_softmax", "vpsa_moe_align", "vpsa_moe_permute", "vpsa_moe_combine",
+            "vpsa_moe_gemv",
         ):
             getattr(lib, name).restype = c_int
         _lib = lib
@@ -324,3 +325,25 @@ def moe_combine(y, weights, pos, tokens):
                                      c_int(tokens), c_int(y.shape[1]), c_int(k), _stream())
     _check(rc, "moe_combine")
     return out
+
+
+def moe_experts_small_batch(x, w13, w2, ids, weights):
+    """Expert MLP for a handful of tokens (decode): out[t] = sum_k weights[t,k] * MLP_{ids[t,k]}(x[t]).
+
+    x [T, H] bf16, w13 [E, 2I, H] (gate rows then up rows), w2 [E, H, I], ids [T, K] int32,
+    weights [T, K] fp32.  On the GPU only the routed experts' weights are streamed (two GEMV
+    kernels + the weighted combine); no host synchronisation, HIP-graph capturable."""
+    t, k = ids.shape
+    if not x.is_cuda:
+        return reference.moe_experts(x, w13, w2, ids, weights)
+    _bf16_cuda(x, w13, w2)
+    hidden, inter = x.shape[1], w2.shape[2]
+    assert w13.shape[1] == 2 * inter and w13.shape[2] == hidden and w2.shape[1] == hidden
+    assert w13.is_contiguous() and w2.is_contiguous() and ids.dtype == torch.int32
+    act = torch.empty((t * k, inter), dtype=x.dtype, device=x.device)
+    y = torch.empty((t * k, hidden), dtype=x.dtype, device=x.device)
+    rc = _kernels().vpsa_moe_gemv(_p(x.contiguous()), _p(w13), _p(w2), _p(ids.contiguous()), _p(act), _p(y),
+                                  c_int(t), c_int(k), c_int(hidden), c_int(inter), _stream())
+    _check(rc, "moe_gemv")
+    pos = torch.arange(t * k, dtype=torch.int32, device=x.device)
+    return moe_combine(y, weights, pos, t)

@@ -181,3 +181,17 @@ def cachegen_decode(symbols, scales, unit_elems, dtype=torch.bfloat16):
     base = q[a] * scales[a][:, None]
     delta = torch.where((tok == 0)[:, None], torch.zeros_like(q), q * scales[:, None])
     return (base + delta).to(dtype).view(-1)
+
+
+def moe_experts(x, w13, w2, ids, weights):
+    """out[t] = sum_k weights[t,k] * W2[e] . (silu(Wg[e] x) * (Wu[e] x)),  e = ids[t,k]."""
+    t, k = ids.shape
+    inter = w2.shape[2]
+    out = torch.zeros((t, x.shape[1]), dtype=torch.float32, device=x.device)
+    for ti in range(t):
+        for ki in range(k):
+            e = int(ids[ti, ki])
+            gu = (w13[e].float() @ x[ti].float()).to(x.dtype).float()
+            a = (torch.nn.functional.silu(gu[:inter]) * gu[inter:]).to(x.dtype).float()
+            out[ti] += float(weights[ti, ki]) * (w2[e].float() @ a).to(x.dtype).float()
+    return out.to(x.dtype)
