@@ -28,9 +28,11 @@ def http(url, body=None, timeout=600):
         return json.loads(r.read() or b"{}")
 
 
-def wait_http(url, timeout):
+def wait_http(url, timeout, proc=None):
     t0 = time.time()
     while time.time() - t0 < timeout:
+        if proc is not None and proc.poll() is not None:
+            raise RuntimeError(f"process behind {url} exited with code {proc.returncode}")
         try:
             urllib.request.urlopen(url, timeout=2).read()  # noqa: S310
             return
@@ -53,12 +55,17 @@ def main():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     pp, dp, rp = a.base_port + 1, a.base_port + 2, a.base_port
     common = [sys.executable, "-m", "vllm_production_stack_amd.engine.cli", "serve", a.model, "--host", "127.0.0.1",
-              "--max-model-len", "32000", "--enable-prefix-caching", "--log-level", "info",
-              "--gpu-memory-utilization", str(a.gpu_memory_utilization)]
+              "--max-model-len", "32000", "--enable-prefix-caching", "--log-level", "info"]
     if a.device != "cuda":
         common += ["--device", "cpu", "--dtype", "float32"]
     procs = []
     logs = {}
+    log_dir = os.environ.get("PD_LOG_DIR") or (os.path.join(ROOT, "gpurun_out") if os.path.isdir(
+        os.path.join(ROOT, "gpurun_out")) else "/tmp")
+
+    def say(msg):
+        print(f"[pd_e2e {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
     try:
         for name, port, role, gpu in (("decode", dp, "receiver", 1), ("prefill", pp, "sender", 0)):
             e = dict(env, LMCACHE_ENABLE_NIXL="True", LMCACHE_NIXL_ROLE=role, LMCACHE_NIXL_RECEIVER_HOST="127.0.0.1",
@@ -66,12 +73,16 @@ def main():
             if a.two_gpus:
                 e["HIP_VISIBLE_DEVICES"] = str(gpu)
             kv_role = "kv_producer" if role == "sender" else "kv_consumer"
-            logs[name] = open(f"/tmp/pd_{name}.log", "w")
+            logs[name] = open(os.path.join(log_dir, f"pd_{name}.log"), "w")
+            say(f"starting {name} engine on port {port}")
+            # --gpu-memory-utilization caps the device's TOTAL use: on a shared card the second
+            # replica's cap has to include what the first one already took
+            util = a.gpu_memory_utilization if (a.two_gpus or name == "decode") else 2 * a.gpu_memory_utilization
             procs.append(subprocess.Popen(
-                common + ["--port", str(port), "--kv-transfer-config",
+                common + ["--gpu-memory-utilization", str(util), "--port", str(port), "--kv-transfer-config",
                           json.dumps({"kv_connector": "LMCacheConnectorV1", "kv_role": kv_role})],
                 env=e, cwd=ROOT, stdout=logs[name], stderr=subprocess.STDOUT))
-            wait_http(f"http://127.0.0.1:{port}/health", 600)  # one at a time: each sizes its pool from free HBM
+            wait_http(f"http://127.0.0.1:{port}/health", 600, procs[-1])  # one at a time: each sizes its pool from free HBM
         procs.append(subprocess.Popen(
             [sys.executable, "-m", "vllm_production_stack_amd.router.app", "--host", "127.0.0.1", "--port", str(rp),
              "--service-discovery", "static", "--static-backends", f"http://127.0.0.1:{pp},http://127.0.0.1:{dp}",
@@ -79,6 +90,7 @@ def main():
              "--routing-logic", "disaggregated_prefill", "--prefill-model-labels", "prefill",
              "--decode-model-labels", "decode", "--log-level", "warning"], env=env, cwd=ROOT))
         wait_http(f"http://127.0.0.1:{rp}/health", 60)
+        say("router up; sending requests")
 
         # prompts as token-id lists (completions API accepts them), distinct per request
         import random
@@ -89,10 +101,11 @@ def main():
             ids = [rng.randrange(16, 400) for _ in range(a.prompt_tokens)]
             body = {"model": a.model, "prompt": ids, "max_tokens": a.max_tokens, "temperature": 0}
             t0 = time.time()
-            out = http(f"http://127.0.0.1:{rp}/v1/completions", body)
+            out = http(f"http://127.0.0.1:{rp}/v1/completions", body, timeout=120)
             dt = time.time() - t0
+            say(f"request {i}: {dt:.3f}s")
             # the same prompt straight to the prefill replica (it holds the KV): reference answer
-            ref = http(f"http://127.0.0.1:{pp}/v1/completions", body)
+            ref = http(f"http://127.0.0.1:{pp}/v1/completions", body, timeout=120)
             usage = out.get("usage", {})
             results.append({"seconds": round(dt, 4), "same_text_as_self_computed": out["choices"][0]["text"] == ref["choices"][0]["text"],
                             "cached_tokens": (usage.get("prompt_tokens_details") or {}).get("cached_tokens")})
@@ -118,7 +131,7 @@ def main():
         for f in logs.values():
             f.close()
         for name in logs:
-            with open(f"/tmp/pd_{name}.log") as f:
+            with open(os.path.join(log_dir, f"pd_{name}.log")) as f:
                 tail = [l for l in f.read().splitlines() if "pushed" in l or "ERROR" in l or "rror" in l][-5:]
             for l in tail:
                 print(f"[{name}] {l}", file=sys.stderr)
