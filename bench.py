@@ -230,13 +230,14 @@ async def rank_main(a: argparse.Namespace) -> None:
             warm = [r["ttft"] for r in rows if r["ttft"] >= 0 and r["question_id"] > 1]
             cold = [r["ttft"] for r in rows if r["ttft"] >= 0 and r["question_id"] == 1]
             users_total = a.users_per_gpu * n
+            model_label = "Llama-3-8B" if a.model == "llama-3-8b" else a.model
             result = {
-                "metric": "output tok/s (+ p50 TTFT), multi-round QA, Llama-3-8B, router + N engine replicas",
+                "metric": f"output tok/s (+ p50 TTFT), multi-round QA, {model_label}, router + N engine replicas",
                 "value": round(out_tokens / elapsed, 2), "unit": "tokens/s", "n_gpus": n,
                 "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if on_gpu else "fp32",
-                "data": "synthetic multi-turn prompts; random-init Llama-3-8B weights",
+                "data": f"synthetic multi-turn prompts; random-init {model_label} weights",
                 "p50_ttft_s": round(mrq.pct(ttfts, 0.5), 4),
                 "mean_ttft_s": round(sum(ttfts) / max(1, len(ttfts)), 4),
                 "p90_ttft_s": round(mrq.pct(ttfts, 0.9), 4),
@@ -245,7 +246,7 @@ async def rank_main(a: argparse.Namespace) -> None:
                 "input_tok_per_s": round(in_tokens / elapsed, 1), "requests": len(rows),
                 "failed_requests": len(bad), "elapsed_s": round(elapsed, 3),
                 "round_times_s": [round(x, 3) for x in outs[0]["round_times"]] if outs else [],
-                "config": {"model": "Llama-3-8B" if a.model == "llama-3-8b" else a.model, "global_batch": users_total,
+                "config": {"model": model_label, "global_batch": users_total,
                            "seq_len": a.sys_len + a.history_len, "answer_len": a.answer_len,
                            "rounds": a.steps, "parallelism": f"dp{n} (replicas behind router)",
                            "routing": a.routing_logic,
