@@ -14,6 +14,8 @@
 // are issued on a dedicated non-blocking stream and fenced with events, never with a
 // device-wide synchronise.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <stdint.h>
 #include <string.h>
 
@@ -26,7 +28,13 @@
 namespace {
 
 struct Pool {
-  char* base = nullptr;
+  // pinned memory comes in slabs of ~1 GiB: one huge hipHostMalloc can fail where many
+  // moderate ones succeed, and a pool that cannot reach its configured size still works
+  std::vector<char*> slabs;
+  size_t slots_per_slab = 1;
+  char* slot_addr(int64_t slot) const {
+    return slabs[(size_t)slot / slots_per_slab] + ((size_t)slot % slots_per_slab) * slot_bytes;
+  }
   size_t slot_bytes = 0;
   size_t n_slots = 0;
   std::vector<int64_t> free_list;
@@ -48,12 +56,32 @@ API void* kvio_pool_create(int device, size_t slot_bytes, size_t n_slots) {
     delete p;
     return nullptr;
   }
-  if (hipHostMalloc((void**)&p->base, slot_bytes * n_slots, hipHostMallocDefault) != hipSuccess) {
+  p->slots_per_slab = std::max<size_t>(1, ((size_t)1 << 30) / slot_bytes);
+  size_t got = 0;
+  while (got < n_slots) {
+    const size_t n = std::min(p->slots_per_slab, n_slots - got);
+    char* slab = nullptr;
+    if (hipHostMalloc((void**)&slab, slot_bytes * n, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      // The host's lockable memory is exhausted.  Give some back: the runtime, the GEMM library
+      // and the engine's own staging buffers pin memory too and fail hard when none is left.
+      for (int k = 0; k < 4 && p->slabs.size() > 4; ++k) {
+        hipHostFree(p->slabs.back());
+        p->slabs.pop_back();
+        got -= p->slots_per_slab;
+      }
+      break;
+    }
+    p->slabs.push_back(slab);
+    got += n;
+  }
+  if (got == 0) {
     delete p;
     return nullptr;
   }
+  p->n_slots = n_slots = got;
   if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) {
-    hipHostFree(p->base);
+    for (char* sl : p->slabs) hipHostFree(sl);
     delete p;
     return nullptr;
   }
@@ -62,12 +90,15 @@ API void* kvio_pool_create(int device, size_t slot_bytes, size_t n_slots) {
   return p;
 }
 
+// Slots actually pinned (<= the requested count when the host refuses more locked memory).
+API int64_t kvio_pool_num_slots(void* h) { return h ? (int64_t) static_cast<Pool*>(h)->n_slots : 0; }
+
 API void kvio_pool_destroy(void* h) {
   Pool* p = static_cast<Pool*>(h);
   if (!p) return;
   hipStreamSynchronize(p->stream);
   hipStreamDestroy(p->stream);
-  hipHostFree(p->base);
+  for (char* sl : p->slabs) hipHostFree(sl);
   delete p;
 }
 
@@ -95,7 +126,7 @@ API size_t kvio_pool_free_slots(void* h) {
 API void* kvio_pool_slot_ptr(void* h, int64_t slot) {
   Pool* p = static_cast<Pool*>(h);
   if (slot < 0 || (size_t)slot >= p->n_slots) return nullptr;
-  return p->base + (size_t)slot * p->slot_bytes;
+  return p->slot_addr(slot);
 }
 
 API void* kvio_pool_stream(void* h) { return static_cast<Pool*>(h)->stream; }
@@ -129,7 +160,7 @@ API int kvio_offload_pages(void* h, const void* dev_base, size_t page_bytes, con
   if (wait_event && hipStreamWaitEvent(p->stream, (hipEvent_t)wait_event, 0) != hipSuccess) return -2;
   for (int i = 0; i < n; ++i) {
     const char* src = (const char*)dev_base + (size_t)page_ids[i] * page_bytes;
-    char* dst = p->base + (size_t)slots[i] * p->slot_bytes;
+    char* dst = p->slot_addr(slots[i]);
     if (hipMemcpyAsync(dst, src, page_bytes, hipMemcpyDeviceToHost, p->stream) != hipSuccess) return -3;
   }
   if (done_event && hipEventRecord((hipEvent_t)done_event, p->stream) != hipSuccess) return -4;
@@ -144,7 +175,7 @@ API int kvio_load_pages(void* h, void* dev_base, size_t page_bytes, const int64_
   if (wait_event && hipStreamWaitEvent(p->stream, (hipEvent_t)wait_event, 0) != hipSuccess) return -2;
   for (int i = 0; i < n; ++i) {
     char* dst = (char*)dev_base + (size_t)page_ids[i] * page_bytes;
-    const char* src = p->base + (size_t)slots[i] * p->slot_bytes;
+    const char* src = p->slot_addr(slots[i]);
     if (hipMemcpyAsync(dst, src, page_bytes, hipMemcpyHostToDevice, p->stream) != hipSuccess) return -3;
   }
   if (done_event && hipEventRecord((hipEvent_t)done_event, p->stream) != hipSuccess) return -4;

@@ -9,6 +9,7 @@ Host tier: on a GPU the pool is one ``hipHostMalloc`` slab managed by ``libvpsa_
 from __future__ import annotations
 
 import ctypes
+import logging
 import os
 from collections import OrderedDict
 from ctypes import c_int, c_int64, c_size_t, c_void_p
@@ -16,6 +17,8 @@ from ctypes import c_int, c_int64, c_size_t, c_void_p
 import torch
 
 from .serde import kvio
+
+log = logging.getLogger("vpsa.kv")
 
 
 class _Event:
@@ -71,6 +74,14 @@ class HostKVPool:
             self.h = c_void_p(lib.kvio_pool_create(pool.device.index or 0, self.page_bytes, self.n_slots))
             if not self.h:
                 raise MemoryError(f"could not pin {self.n_slots * self.page_bytes >> 20} MiB of host memory")
+            lib.kvio_pool_num_slots.restype = c_int64
+            lib.kvio_pool_num_slots.argtypes = [c_void_p]
+            got = int(lib.kvio_pool_num_slots(self.h))
+            if got < self.n_slots:
+                log.warning("host KV tier: pinned %d of %d requested pages (%.1f of %.1f GiB); the host "
+                            "refuses more locked memory", got, self.n_slots, got * self.page_bytes / 2**30,
+                            self.n_slots * self.page_bytes / 2**30)
+                self.n_slots = got
             self.free_slots = list(range(self.n_slots - 1, -1, -1))
         else:
             self.host = torch.empty((self.n_slots, *pool.shape[1:]), dtype=pool.dtype)
