@@ -105,8 +105,13 @@ def decode_case(n_seqs: int, ctx: int, iters: int) -> dict:
         def run():
             ops.paged_decode(q, out, pool, 0, bt, ctxs, N_Q, N_KV, HD, scale, splits, ws_o, ws_ml)
 
-        ms = timed(run, iters)
-        res[f"splits{splits}"] = {"ms": round(ms, 4), "tb_per_s": round(kv_bytes / ms / 1e9, 3)}
+        entry = {}
+        for dv in (0, 1):
+            ops.set_decode_variant(dv)
+            ms = timed(run, iters)
+            entry[f"v{dv}"] = {"ms": round(ms, 4), "tb_per_s": round(kv_bytes / ms / 1e9, 3)}
+        ops.set_decode_variant(0)
+        res[f"splits{splits}"] = entry
     res["default_splits"] = ops.decode_num_splits(n_seqs, N_KV, ctx)
     return res
 

@@ -508,6 +508,7 @@ VPSA_EXPORT int vpsa_paged_prefill(const void* q, long q_stride, void* out, long
 // grid = (num_seqs, n_kv, num_splits); block = 256 (4 waves, interleaved over 32-key chunks).
 // Requires G = n_q / n_kv <= 16.
 // ---------------------------------------------------------------------------------
+template <bool PIPE>
 __global__ __launch_bounds__(256) void paged_decode_kernel(
     const uint16_t* __restrict__ q, long q_stride, uint16_t* __restrict__ out, long out_stride,
     const uint16_t* __restrict__ cache, long page_stride, long v_offset,
@@ -560,12 +561,11 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
   // MFMA row rho = c16 of key sub-tile t reads key 8*(rho>>2) + 4t + (rho&3)
   const int krow_base = 8 * (c16 >> 2) + (c16 & 3);
 
-  for (int c = c_begin + wave; c < c_end; c += 4) {
+  auto load_chunk = [&](int c, u32x4 (&kf)[2][4], u32x4 (&vf)[8]) {
     const long page = bt[c >> 1];
     const int koff = (c & 1) * 32;
     const uint16_t* kp = cache + page * page_stride + (long)kvh * PAGE * HEAD_DIM;
     const uint16_t* vp = cache + page * page_stride + v_offset + (long)kvh * HEAD_DIM * PAGE;
-    u32x4 kf[2][4], vf[8];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -575,7 +575,8 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt)
       vf[dt] = *reinterpret_cast<const u32x4*>(vp + (16 * dt + c16) * PAGE + koff + 8 * g);
-
+  };
+  auto compute_chunk = [&](int c, u32x4 (&kf)[2][4], u32x4 (&vf)[8]) {
     f32x4 s_acc[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -623,6 +624,28 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
       o_acc[dt] *= alpha;
       o_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf[dt]), pf,
                                                          o_acc[dt], 0, 0, 0);
+    }
+  };
+
+  if (PIPE) {
+    // two register sets: the loads of the wave's next chunk are in flight while the current
+    // one is multiplied (the wave count per SIMD drops, each wave keeps twice the bytes in flight)
+    u32x4 kfa[2][4], vfa[8], kfb[2][4], vfb[8];
+    int c = c_begin + wave;
+    if (c < c_end) load_chunk(c, kfa, vfa);
+    for (; c < c_end; c += 8) {
+      if (c + 4 < c_end) load_chunk(c + 4, kfb, vfb);
+      compute_chunk(c, kfa, vfa);
+      if (c + 4 < c_end) {
+        if (c + 8 < c_end) load_chunk(c + 8, kfa, vfa);
+        compute_chunk(c + 4, kfb, vfb);
+      }
+    }
+  } else {
+    u32x4 kf[2][4], vf[8];
+    for (int c = c_begin + wave; c < c_end; c += 4) {
+      load_chunk(c, kf, vf);
+      compute_chunk(c, kf, vf);
     }
   }
 
@@ -697,6 +720,14 @@ __global__ __launch_bounds__(128) void decode_reduce_kernel(const float* __restr
   out[(long)seq * out_stride + head * HEAD_DIM + d] = __builtin_bit_cast(uint16_t, b);
 }
 
+// 0 = one register set per wave, 1 = software-pipelined (two register sets)
+static int g_decode_variant = 0;
+VPSA_EXPORT int vpsa_set_decode_variant(int v) {
+  const int old = g_decode_variant;
+  g_decode_variant = v;
+  return old;
+}
+
 VPSA_EXPORT int vpsa_paged_decode(const void* q, long q_stride, void* out, long out_stride,
                                   const void* cache, long page_stride, long v_offset,
                                   const int* block_tables, int max_blocks, const int* ctx_lens,
@@ -706,7 +737,14 @@ VPSA_EXPORT int vpsa_paged_decode(const void* q, long q_stride, void* out, long 
   if (n_q % n_kv != 0 || n_q / n_kv > 16 || num_splits < 1) return -1;
   if (num_splits > 1 && (!ws_o || !ws_ml)) return -1;
   dim3 grid(num_seqs, n_kv, num_splits), block(256);
-  hipLaunchKernelGGL(paged_decode_kernel, grid, block, 32768 + 512, stream, (const uint16_t*)q,
+  if (g_decode_variant == 1) {
+    hipLaunchKernelGGL(paged_decode_kernel<true>, grid, block, 32768 + 512, stream,
+                       (const uint16_t*)q, q_stride, (uint16_t*)out, out_stride,
+                       (const uint16_t*)cache, page_stride, v_offset, block_tables, max_blocks,
+                       ctx_lens, (float*)ws_o, (float*)ws_ml, n_q, n_kv, num_splits,
+                       scale * 1.4426950408889634f);
+  } else
+  hipLaunchKernelGGL(paged_decode_kernel<false>, grid, block, 32768 + 512, stream, (const uint16_t*)q,
                      q_stride, (uint16_t*)out, out_stride, (const uint16_t*)cache, page_stride,
                      v_offset, block_tables, max_blocks, ctx_lens, (float*)ws_o, (float*)ws_ml,
                      n_q, n_kv, num_splits, scale * 1.4426950408889634f);

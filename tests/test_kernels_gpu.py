@@ -139,7 +139,8 @@ def test_paged_prefill_forced_rescale():
 
 @pytest.mark.parametrize("n_q,n_kv", [(32, 8), (8, 8), (64, 8)])
 @pytest.mark.parametrize("splits", [1, 3, 8])
-def test_paged_decode_matches_reference(n_q, n_kv, splits):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_paged_decode_matches_reference(n_q, n_kv, splits, variant):
     torch.manual_seed(10)
     hd, layers = 128, 2
     ctx = [1, 31, 32, 33, 64, 65, 700, 2049]
@@ -150,7 +151,11 @@ def test_paged_decode_matches_reference(n_q, n_kv, splits):
     ctx_t = torch.tensor(ctx, dtype=torch.int32, device=DEV)
     out, out_ref = torch.zeros_like(q), torch.zeros_like(q)
     scale = 1.0 / math.sqrt(hd)
-    ops.paged_decode(q, out, pool, 1, bt, ctx_t, n_q, n_kv, hd, scale, num_splits=splits)
+    prev = ops.set_decode_variant(variant)
+    try:
+        ops.paged_decode(q, out, pool, 1, bt, ctx_t, n_q, n_kv, hd, scale, num_splits=splits)
+    finally:
+        ops.set_decode_variant(prev)
     ref.paged_decode(q, out_ref, pool, 1, bt, ctx_t, n_q, n_kv, hd, scale)
     err = (out.float() - out_ref.float()).abs().max().item()
     assert err < 3e-2, err

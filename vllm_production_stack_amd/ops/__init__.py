@@ -26,7 +26,7 @@ def _kernels():
         lib = _native.load("vpsa_kernels")
         for name in (
             "vpsa_rmsnorm", "vpsa_rope_cache", "vpsa_silu_mul", "vpsa_argmax_bf16",
-            "vpsa_paged_prefill", "vpsa_set_prefill_variant", "vpsa_paged_decode", "vpsa_kv_gather_pages",
+            "vpsa_paged_prefill", "vpsa_set_prefill_variant", "vpsa_set_decode_variant", "vpsa_paged_decode", "vpsa_kv_gather_pages",
             "vpsa_kv_scatter_pages", "vpsa_cachegen_encode", "vpsa_cachegen_decode",
             "vpsa_moe_topk_softmax", "vpsa_moe_align", "vpsa_moe_permute", "vpsa_moe_combine",
             "vpsa_moe_gemv",
@@ -44,6 +44,12 @@ def set_prefill_variant(v: int) -> int:
     """Select the prefill attention kernel generation (for in-process A/B timing and tests).
     Returns the previous selection."""
     return int(_kernels().vpsa_set_prefill_variant(c_int(v)))
+
+
+def set_decode_variant(v: int) -> int:
+    """Select the decode attention kernel (0: one register set per wave, 1: software-pipelined
+    with two register sets).  Returns the previous selection."""
+    return int(_kernels().vpsa_set_decode_variant(c_int(v)))
 
 
 def _stream():
