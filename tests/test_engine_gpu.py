@@ -145,3 +145,28 @@ def test_ipc_page_push_between_pools():
     while dst.has_work():
         dst.step()
     assert r.num_cached_tokens == 320 and r.output_ids == want
+
+
+def test_speech_model_bf16_tracks_fp32_on_gpu():
+    """Whisper-small shape, random weights: bf16 encoder output and greedy tokens on the GPU
+    against the same weights evaluated in fp32."""
+    import numpy as np
+
+    from vllm_production_stack_amd.models import whisper as W
+
+    cfg, _ = W.resolve_whisper("openai/whisper-small")
+    dev = torch.device("cuda", 0)
+    m32 = W.WhisperModel(cfg, torch.float32, dev)
+    m32.init_random(3)
+    m16 = W.WhisperModel(cfg, torch.bfloat16, dev)
+    m16.w = {k: v.to(torch.bfloat16) for k, v in m32.w.items()}
+    t = np.arange(W.N_SAMPLES) / W.SAMPLE_RATE
+    waves = torch.from_numpy(np.stack([0.3 * np.sin(2 * np.pi * f * t) for f in (220.0, 880.0)]).astype(np.float32))
+    mel = W.log_mel(waves.to(dev), cfg.num_mel_bins, m32.filters)
+    e32, e16 = m32.encode(mel), m16.encode(mel).float()
+    rel = ((e32 - e16).norm() / e32.norm()).item()
+    assert rel < 3e-2, rel
+    prompt = m16.prompt_ids(None)
+    toks = m16.transcribe_windows(waves, [prompt, prompt], max_new_tokens=12)
+    assert len(toks) == 2 and all(len(x) <= 12 for x in toks)
+    assert all(tok < cfg.eos_token_id for x in toks for tok in x)

@@ -1,0 +1,249 @@
+"""Speech-to-text replica: audio decoding, the log-mel front end and the encoder/decoder
+against the Hugging Face implementation of the same architecture (random weights of a tiny
+configuration written to a checkpoint directory and read back through our loader), and the
+HTTP contract directly and through the router."""
+
+import asyncio
+import io
+import struct
+import wave
+
+import aiohttp
+import numpy as np
+import pytest
+import torch
+
+from vllm_production_stack_amd.engine import audio
+from vllm_production_stack_amd.engine.config import EngineConfig
+from vllm_production_stack_amd.models import whisper as W
+
+
+def _tone(seconds=1.0, rate=16000, freq=440.0):
+    t = np.arange(int(seconds * rate)) / rate
+    return (0.3 * np.sin(2 * np.pi * freq * t)).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------- audio decoding
+def test_wav_pcm16_roundtrip_and_stdlib_agreement():
+    x = _tone(0.5)
+    data = audio.pcm16_wav(x)
+    with wave.open(io.BytesIO(data)) as w:  # the standard library reads what we wrote
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (1, 2, 16000)
+        assert w.getnframes() == x.size
+    y, rate = audio.decode_wav(data)
+    assert rate == 16000 and y.shape == x.shape
+    assert np.abs(y - x).max() < 1e-4
+
+
+@pytest.mark.parametrize("bits,tag", [(8, 1), (24, 1), (32, 1), (32, 3)])
+def test_wav_other_encodings(bits, tag):
+    x = _tone(0.1)
+    if tag == 3:
+        body = x.astype("<f4").tobytes()
+    elif bits == 8:
+        body = (x * 127 + 128).astype(np.uint8).tobytes()
+    elif bits == 24:
+        v = (x * (1 << 23)).astype(np.int32)
+        body = b"".join(struct.pack("<i", int(s))[:3] for s in v)
+    else:
+        body = (x.astype(np.float64) * (2**31 - 1)).astype("<i4").tobytes()
+    hdr = struct.pack("<IHHIIHH", 16, tag, 1, 16000, 16000 * bits // 8, bits // 8, bits)
+    data = b"RIFF" + struct.pack("<I", 36 + len(body)) + b"WAVE" + b"fmt " + hdr + b"data" + \
+        struct.pack("<I", len(body)) + body
+    y, _ = audio.decode_wav(data)
+    assert y.shape == x.shape
+    assert np.abs(y - x).max() < (2e-2 if bits == 8 else 1e-4)
+
+
+def test_stereo_downmix_and_resample():
+    x = _tone(0.5, rate=44100)
+    stereo = np.stack([x, x], axis=1).reshape(-1)
+    body = (stereo * 32767).astype("<i2").tobytes()
+    hdr = struct.pack("<IHHIIHH", 16, 1, 2, 44100, 44100 * 4, 4, 16)
+    data = b"RIFF" + struct.pack("<I", 36 + len(body)) + b"WAVE" + b"fmt " + hdr + b"data" + \
+        struct.pack("<I", len(body)) + body
+    y = audio.load_audio(data)
+    assert abs(y.size - 8000) <= 1
+    # still a 440 Hz tone: strongest FFT bin of the resampled signal
+    k = np.abs(np.fft.rfft(y)).argmax()
+    assert abs(k * 16000 / y.size - 440) < 5
+
+
+def test_compressed_containers_are_rejected_with_reason():
+    with pytest.raises(audio.AudioError, match="mp3"):
+        audio.load_audio(b"ID3\x04" + b"\x00" * 64)
+    with pytest.raises(audio.AudioError, match="flac"):
+        audio.load_audio(b"fLaC" + b"\x00" * 64)
+    assert audio.load_audio(audio.silent_wav()).size == 1600
+
+
+# ---------------------------------------------------------------------------- numerics
+def test_log_mel_matches_hf_feature_extractor():
+    from transformers import WhisperFeatureExtractor
+
+    rng = np.random.default_rng(0)
+    x = (_tone(3.0) + 0.05 * rng.standard_normal(48000)).astype(np.float32)
+    for mels in (80, 128):
+        want = WhisperFeatureExtractor(feature_size=mels)(x, sampling_rate=16000,
+                                                          return_tensors="np")["input_features"][0]
+        window = torch.from_numpy(W.pad_or_trim(x)[0])[None]
+        got = W.log_mel(window, mels)[0].numpy()
+        assert got.shape == want.shape == (mels, 3000)
+        assert np.abs(got - want).max() < 2e-3
+
+
+@pytest.fixture(scope="module")
+def hf_checkpoint(tmp_path_factory):
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+
+    torch.manual_seed(0)
+    cfg = WhisperConfig(vocab_size=600, num_mel_bins=80, encoder_layers=2, decoder_layers=2,
+                        encoder_attention_heads=4, decoder_attention_heads=4, d_model=64,
+                        encoder_ffn_dim=128, decoder_ffn_dim=128, max_source_positions=1500,
+                        max_target_positions=64, pad_token_id=0, bos_token_id=1, eos_token_id=2,
+                        decoder_start_token_id=3, suppress_tokens=None, begin_suppress_tokens=None)
+    model = WhisperForConditionalGeneration(cfg).eval()
+    with torch.no_grad():  # non-trivial biases and norms
+        for name, p in model.named_parameters():
+            if name.endswith(".bias") or "layer_norm" in name:
+                p.add_(0.1 * torch.randn_like(p))
+    d = tmp_path_factory.mktemp("hf_whisper")
+    model.save_pretrained(d, safe_serialization=True)
+    return d, model
+
+
+def test_encoder_decoder_match_hf(hf_checkpoint):
+    d, hf = hf_checkpoint
+    cfg, ckpt = W.resolve_whisper(str(d))
+    assert ckpt is not None and cfg.d_model == 64 and cfg.sot_token_id == 3
+    m = W.WhisperModel(cfg, torch.float32, torch.device("cpu"))
+    m.load_hf(ckpt)
+    rng = np.random.default_rng(1)
+    x = (_tone(2.0) + 0.05 * rng.standard_normal(32000)).astype(np.float32)
+    mel = W.log_mel(torch.from_numpy(W.pad_or_trim(x)[0])[None], 80)
+    enc = m.encode(mel)
+    with torch.no_grad():
+        want_enc = hf.model.encoder(mel).last_hidden_state
+    assert (enc - want_enc).abs().max().item() < 2e-4
+    tokens = torch.tensor([[3, 7, 5, 6, 100, 200, 321]])
+    with torch.no_grad():
+        want = hf(input_features=mel, decoder_input_ids=tokens).logits
+    cross = m.cross_kv(enc)
+    # whole prefix at once, and prefix + one cached step: both must give HF's last-row logits
+    got_full = m.decode(tokens, 0, cross, [None] * cfg.decoder_layers)
+    assert (got_full - want[:, -1]).abs().max().item() < 2e-4
+    cache = [None] * cfg.decoder_layers
+    m.decode(tokens[:, :-1], 0, cross, cache)
+    got_step = m.decode(tokens[:, -1:], tokens.shape[1] - 1, cross, cache)
+    assert (got_step - want[:, -1]).abs().max().item() < 2e-4
+
+
+def test_greedy_transcription_matches_hf_greedy_loop(hf_checkpoint):
+    d, hf = hf_checkpoint
+    cfg, ckpt = W.resolve_whisper(str(d))
+    cfg.suppress_lo, cfg.suppress_hi = 3, 16
+    m = W.WhisperModel(cfg, torch.float32, torch.device("cpu"))
+    m.load_hf(ckpt)
+    rng = np.random.default_rng(2)
+    waves = np.stack([W.pad_or_trim((_tone(1.0, freq=f) + 0.05 * rng.standard_normal(16000)).astype(np.float32))[0]
+                      for f in (300.0, 900.0)])
+    prompt = [3, 7, 5, 6]
+    got = m.transcribe_windows(torch.from_numpy(waves), [prompt, prompt], max_new_tokens=8)
+    mel = W.log_mel(torch.from_numpy(waves), 80)
+    for b in range(2):
+        ids = list(prompt)
+        out = []
+        for _ in range(8):
+            with torch.no_grad():
+                logits = hf(input_features=mel[b: b + 1], decoder_input_ids=torch.tensor([ids])).logits[0, -1]
+            logits[3:16] = float("-inf")
+            t = int(logits.argmax())
+            if t == 2:
+                break
+            out.append(t)
+            ids.append(t)
+        assert got[b] == out
+
+
+# ---------------------------------------------------------------------------- HTTP contract
+def _run(coro):
+    return asyncio.run(coro)
+
+
+async def _post_audio(session, url, wav, **fields):
+    form = aiohttp.FormData()
+    form.add_field("file", wav, filename="a.wav", content_type="audio/wav")
+    for k, v in fields.items():
+        form.add_field(k, str(v))
+    async with session.post(url, data=form) as r:
+        ct = r.headers.get("Content-Type", "")
+        return r.status, (await r.json() if "json" in ct else await r.text())
+
+
+def test_speech_server_contract_and_router_proxy():
+    from vllm_production_stack_amd.engine.speech import SpeechEngine, serve_speech
+    from vllm_production_stack_amd.router.app import create_app
+    from vllm_production_stack_amd.router.config import parse_args
+    from aiohttp import web
+
+    async def go():
+        cfg = EngineConfig(model="tiny-whisper", served_model_name="openai/whisper-small", device="cpu",
+                           dtype="float32", host="127.0.0.1", port=0, enable_sleep_mode=True)
+        engine = SpeechEngine(cfg)
+        runner = await serve_speech(engine, "127.0.0.1", 0)
+        port = runner.addresses[0][1]
+        base = f"http://127.0.0.1:{port}"
+        wav = audio.pcm16_wav(np.concatenate([_tone(1.0), _tone(31.0, freq=700)]))  # two windows
+        async with aiohttp.ClientSession() as s:
+            async with s.get(base + "/v1/models") as r:
+                cards = (await r.json())["data"]
+                assert cards[0]["id"] == "openai/whisper-small" and cards[0]["parent"] is None
+            st, body = await _post_audio(s, base + "/v1/audio/transcriptions", wav,
+                                         model="openai/whisper-small", language="en")
+            assert st == 200 and isinstance(body["text"], str) and body["text"]
+            st, verbose = await _post_audio(s, base + "/v1/audio/transcriptions", wav,
+                                            model="openai/whisper-small", response_format="verbose_json")
+            assert st == 200 and len(verbose["segments"]) == 2 and verbose["duration"] == 32.0
+            assert verbose["text"] == body["text"]  # greedy decoding is deterministic
+            st, srt = await _post_audio(s, base + "/v1/audio/transcriptions", wav,
+                                        model="openai/whisper-small", response_format="srt")
+            assert st == 200 and "00:00:00,000 --> 00:00:30,000" in srt
+            st, _ = await _post_audio(s, base + "/v1/audio/transcriptions", b"ID3\x04junk",
+                                      model="openai/whisper-small")
+            assert st == 400
+            st, _ = await _post_audio(s, base + "/v1/audio/transcriptions", wav, model="other")
+            assert st == 404
+            st, _ = await _post_audio(s, base + "/v1/audio/transcriptions", wav,
+                                      model="openai/whisper-small", language="xx")
+            assert st == 400
+            async with s.post(base + "/v1/chat/completions", json={"messages": []}) as r:
+                assert r.status == 400
+            async with s.get(base + "/metrics") as r:
+                assert "vllm:num_requests_waiting" in await r.text()
+            async with s.post(base + "/sleep?level=1") as r:
+                assert r.status == 200
+            async with s.get(base + "/is_sleeping") as r:
+                assert (await r.json())["is_sleeping"] is True
+            st, _ = await _post_audio(s, base + "/v1/audio/transcriptions", wav, model="openai/whisper-small")
+            assert st == 503
+            async with s.post(base + "/wake_up") as r:
+                assert r.status == 200
+
+            # through the router: static discovery with a transcription-typed backend
+            args = parse_args(["--port", "0", "--service-discovery", "static",
+                               "--static-backends", base, "--static-models", "openai/whisper-small",
+                               "--static-model-types", "transcription", "--routing-logic", "roundrobin"])
+            app = create_app(args)
+            rr = web.AppRunner(app)
+            await rr.setup()
+            site = web.TCPSite(rr, "127.0.0.1", 0)
+            await site.start()
+            rport = rr.addresses[0][1]
+            st, via = await _post_audio(s, f"http://127.0.0.1:{rport}/v1/audio/transcriptions", wav,
+                                        model="openai/whisper-small", language="en")
+            assert st == 200 and via["text"] == body["text"]
+            await rr.cleanup()
+        await runner.cleanup()
+        engine.shutdown()
+
+    _run(go())

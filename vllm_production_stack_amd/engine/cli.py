@@ -94,6 +94,13 @@ async def run_server(cfg: EngineConfig, ready: "asyncio.Event | None" = None) ->
     from .llm_engine import LLMEngine
     from .server import serve
 
+    from ..models.whisper import is_whisper_name
+
+    if is_whisper_name(cfg.model):
+        await _run_speech_server(cfg, ready)
+        return
+    if cfg.task == "transcription":
+        raise ValueError(f"--task transcription needs a speech model; {cfg.model!r} is a text model")
     world = cfg.tensor_parallel_size * max(1, cfg.pipeline_parallel_size)
     if world > 1:
         from ..parallel.launch import init_parallel_from_env
@@ -131,6 +138,25 @@ async def run_server(cfg: EngineConfig, ready: "asyncio.Event | None" = None) ->
     await stop.wait()
     await runner.cleanup()
     ae.stop()
+
+
+async def _run_speech_server(cfg: EngineConfig, ready=None) -> None:
+    from .speech import SpeechEngine, serve_speech
+
+    engine = SpeechEngine(cfg)
+    runner = await serve_speech(engine, cfg.host, cfg.port)
+    loop = asyncio.get_running_loop()
+    stop = asyncio.Event()
+    for sig in (signal.SIGINT, signal.SIGTERM):
+        try:
+            loop.add_signal_handler(sig, stop.set)
+        except (NotImplementedError, RuntimeError):
+            pass
+    if ready is not None:
+        ready.set()
+    await stop.wait()
+    await runner.cleanup()
+    engine.shutdown()
 
 
 def main(argv: list[str] | None = None) -> None:

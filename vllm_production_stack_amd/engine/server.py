@@ -553,27 +553,10 @@ class EngineServer:
                                   "usage": {"prompt_tokens": total, "total_tokens": total}})
 
     async def transcriptions(self, request):
-        """Speech-to-text needs an audio encoder model; text decoders answer with a clear
-        501 unless the replica was started with --task transcription, in which case the
-        audio is validated and an (empty-speech) transcript is produced for silent input."""
-        if self.cfg.task != "transcription":
-            return _err(501, "this replica does not serve a transcription model", "NotImplementedError")
-        reader = await request.multipart()
-        fields, audio = {}, b""
-        async for part in reader:
-            if part.name == "file":
-                audio = await part.read(decode=False)
-            else:
-                fields[part.name] = (await part.read(decode=False)).decode(errors="replace")
-        if not audio:
-            return _err(400, "missing audio file")
-        from .audio import transcribe_pcm
-
-        text = transcribe_pcm(audio, fields.get("language"))
-        fmt = fields.get("response_format", "json")
-        if fmt == "text":
-            return web.Response(text=text)
-        return web.json_response({"text": text})
+        """Text decoders do not transcribe: a speech model is served by the speech replica
+        (engine/speech.py), which `serve` starts for Whisper-class models."""
+        return _err(501, "this replica does not serve a transcription model; start one with "
+                         "`serve openai/whisper-small --task transcription`", "NotImplementedError")
 
 
 def sanitize_float(x: float) -> float:

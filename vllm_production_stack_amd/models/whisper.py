@@ -1,0 +1,425 @@
+"""Whisper-class speech-to-text model (audio encoder + text decoder with cross-attention).
+
+Serves ``POST /v1/audio/transcriptions`` for replicas started with a speech model
+(``--task transcription``; the reference proxies that route to such a replica:
+/root/reference/src/vllm_router/services/request_service/request.py:513-689, and its
+tutorial deploys ``openai/whisper-small``: /root/reference/tutorials/23-whisper-api-transcription.md:20-30).
+
+Shape of the work: the encoder sees a fixed 30 s window (3000 mel frames -> 1500 positions),
+so a batch of windows is one dense [B, 1500, d] problem; the decoder emits at most 448 tokens
+against a cross-attention K/V that is computed once per window.  Everything is dense
+(no paged pool): the weights are <= 3 GiB, a window's cross K/V is <= 1500 x d per layer, and
+the matmuls go to the library GEMM.  Attention is written out as two batched GEMMs and a
+softmax so that no hidden JIT kernel is involved.
+
+Weights follow the Hugging Face layout (``model.encoder.*`` / ``model.decoder.*``) when a
+checkpoint directory is given; otherwise they are drawn from a seeded generator.
+"""
+
+from __future__ import annotations
+
+import json
+import math
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SAMPLE_RATE = 16000
+N_FFT = 400
+HOP = 160
+CHUNK_SECONDS = 30
+N_SAMPLES = SAMPLE_RATE * CHUNK_SECONDS
+N_FRAMES = N_SAMPLES // HOP  # 3000
+
+
+@dataclass
+class WhisperConfig:
+    name: str = "tiny-whisper"
+    vocab_size: int = 51865
+    num_mel_bins: int = 80
+    d_model: int = 384
+    encoder_layers: int = 4
+    decoder_layers: int = 4
+    encoder_heads: int = 6
+    decoder_heads: int = 6
+    encoder_ffn_dim: int = 1536
+    decoder_ffn_dim: int = 1536
+    max_source_positions: int = 1500
+    max_target_positions: int = 448
+    eos_token_id: int = 50257
+    sot_token_id: int = 50258  # <|startoftranscript|>
+    transcribe_token_id: int = 50359
+    translate_token_id: int = 50358
+    no_timestamps_token_id: int = 50363
+    first_language_token_id: int = 50259  # <|en|>
+    # ids in [suppress_lo, suppress_hi) are control tokens (start, languages, tasks, timestamps)
+    # and are never emitted in no-timestamps transcription; 0 = (eos+1, vocab_size)
+    suppress_lo: int = 0
+    suppress_hi: int = 0
+    architecture: str = "whisper"
+
+    def num_params(self) -> int:
+        d = self.d_model
+        enc = self.encoder_layers * (4 * d * d + 2 * d * self.encoder_ffn_dim)
+        dec = self.decoder_layers * (8 * d * d + 2 * d * self.decoder_ffn_dim)
+        return enc + dec + self.vocab_size * d
+
+
+def _multilingual(name, d, layers, heads, vocab=51865, mels=80, **kw) -> WhisperConfig:
+    return WhisperConfig(name=name, vocab_size=vocab, num_mel_bins=mels, d_model=d,
+                         encoder_layers=layers, decoder_layers=layers, encoder_heads=heads,
+                         decoder_heads=heads, encoder_ffn_dim=4 * d, decoder_ffn_dim=4 * d, **kw)
+
+
+WHISPER_PRESETS: dict[str, WhisperConfig] = {
+    "whisper-tiny": _multilingual("whisper-tiny", 384, 4, 6),
+    "whisper-base": _multilingual("whisper-base", 512, 6, 8),
+    "whisper-small": _multilingual("whisper-small", 768, 12, 12),
+    "whisper-medium": _multilingual("whisper-medium", 1024, 24, 16),
+    "whisper-large-v2": _multilingual("whisper-large-v2", 1280, 32, 20),
+    # large-v3: 128 mel bins and one more language token, so the task tokens move up by one
+    "whisper-large-v3": _multilingual("whisper-large-v3", 1280, 32, 20, vocab=51866, mels=128,
+                                      transcribe_token_id=50360, translate_token_id=50359,
+                                      no_timestamps_token_id=50364),
+    "tiny-whisper": WhisperConfig(name="tiny-whisper", vocab_size=600, d_model=64, encoder_layers=2,
+                                  decoder_layers=2, encoder_heads=4, decoder_heads=4,
+                                  encoder_ffn_dim=128, decoder_ffn_dim=128, max_target_positions=64,
+                                  eos_token_id=2, sot_token_id=3, transcribe_token_id=5,
+                                  translate_token_id=4, no_timestamps_token_id=6,
+                                  first_language_token_id=7, suppress_lo=3, suppress_hi=16),
+}
+
+
+def is_whisper_name(model: str) -> bool:
+    base = model.lower().rstrip("/").split("/")[-1]
+    return "whisper" in base
+
+
+def resolve_whisper(model: str) -> tuple[WhisperConfig, Path | None]:
+    """Model id or checkpoint directory -> (config, directory or None for random weights)."""
+    p = Path(model)
+    if p.is_dir() and (p / "config.json").exists():
+        with open(p / "config.json") as f:
+            c = json.load(f)
+        cfg = WhisperConfig(
+            name=model, vocab_size=c["vocab_size"], num_mel_bins=c.get("num_mel_bins", 80),
+            d_model=c["d_model"], encoder_layers=c["encoder_layers"],
+            decoder_layers=c["decoder_layers"], encoder_heads=c["encoder_attention_heads"],
+            decoder_heads=c["decoder_attention_heads"], encoder_ffn_dim=c["encoder_ffn_dim"],
+            decoder_ffn_dim=c["decoder_ffn_dim"],
+            max_source_positions=c.get("max_source_positions", 1500),
+            max_target_positions=c.get("max_target_positions", 448),
+            eos_token_id=c.get("eos_token_id", 50257),
+            sot_token_id=c.get("decoder_start_token_id", 50258))
+        gen = p / "generation_config.json"
+        if gen.exists():
+            with open(gen) as f:
+                g = json.load(f)
+            t2i = g.get("task_to_id") or {}
+            cfg.transcribe_token_id = t2i.get("transcribe", cfg.transcribe_token_id)
+            cfg.translate_token_id = t2i.get("translate", cfg.translate_token_id)
+            cfg.no_timestamps_token_id = g.get("no_timestamps_token_id", cfg.no_timestamps_token_id)
+            l2i = g.get("lang_to_id") or {}
+            if l2i:
+                cfg.first_language_token_id = min(l2i.values())
+        return cfg, p
+    base = model.lower().rstrip("/").split("/")[-1]
+    for key in sorted(WHISPER_PRESETS, key=len, reverse=True):
+        if key == base or key in base:
+            c = WHISPER_PRESETS[key]
+            return WhisperConfig(**{**c.__dict__, "name": model}), None
+    raise ValueError(f"unknown speech model {model!r}")
+
+
+# ---------------------------------------------------------------------------- audio front end
+def _hz_to_mel(f: np.ndarray) -> np.ndarray:
+    # Slaney scale: linear below 1 kHz, logarithmic above
+    f = np.asarray(f, dtype=np.float64)
+    mel = f / (200.0 / 3)
+    log_region = f >= 1000.0
+    mel[log_region] = 15.0 + np.log(f[log_region] / 1000.0) / (math.log(6.4) / 27.0)
+    return mel
+
+
+def _mel_to_hz(m: np.ndarray) -> np.ndarray:
+    m = np.asarray(m, dtype=np.float64)
+    f = m * (200.0 / 3)
+    log_region = m >= 15.0
+    f[log_region] = 1000.0 * np.exp((math.log(6.4) / 27.0) * (m[log_region] - 15.0))
+    return f
+
+
+def mel_filterbank(n_mels: int, n_fft: int = N_FFT, sr: int = SAMPLE_RATE) -> np.ndarray:
+    """[n_mels, n_fft/2+1] triangular filters on the Slaney mel scale, area-normalised."""
+    fft_freqs = np.linspace(0, sr / 2, n_fft // 2 + 1)
+    mel_pts = _mel_to_hz(np.linspace(_hz_to_mel(np.array([0.0]))[0],
+                                     _hz_to_mel(np.array([sr / 2.0]))[0], n_mels + 2))
+    fdiff = np.diff(mel_pts)
+    ramps = mel_pts[:, None] - fft_freqs[None, :]
+    lower = -ramps[:-2] / fdiff[:-1, None]
+    upper = ramps[2:] / fdiff[1:, None]
+    fb = np.maximum(0.0, np.minimum(lower, upper))
+    fb *= (2.0 / (mel_pts[2:] - mel_pts[:-2]))[:, None]
+    return fb.astype(np.float32)
+
+
+def log_mel(samples: torch.Tensor, n_mels: int, filters: torch.Tensor | None = None) -> torch.Tensor:
+    """[B, N_SAMPLES] float waveform at 16 kHz -> [B, n_mels, 3000] normalised log-mel."""
+    window = torch.hann_window(N_FFT, periodic=True, device=samples.device, dtype=torch.float32)
+    spec = torch.stft(samples.float(), N_FFT, HOP, window=window, center=True, pad_mode="reflect",
+                      return_complex=True)
+    power = spec[..., :-1].abs().pow(2)
+    if filters is None:
+        filters = torch.from_numpy(mel_filterbank(n_mels)).to(samples.device)
+    mel = filters @ power
+    log = torch.clamp(mel, min=1e-10).log10()
+    log = torch.maximum(log, log.amax(dim=(-2, -1), keepdim=True) - 8.0)
+    return (log + 4.0) / 4.0
+
+
+def pad_or_trim(samples: np.ndarray) -> list[np.ndarray]:
+    """Split a waveform into 30 s windows, the last one zero-padded."""
+    if samples.size == 0:
+        return [np.zeros(N_SAMPLES, dtype=np.float32)]
+    out = []
+    for a in range(0, samples.size, N_SAMPLES):
+        w = samples[a: a + N_SAMPLES].astype(np.float32)
+        if w.size < N_SAMPLES:
+            w = np.concatenate([w, np.zeros(N_SAMPLES - w.size, dtype=np.float32)])
+        out.append(w)
+    return out
+
+
+def _sinusoids(length: int, channels: int) -> torch.Tensor:
+    inc = math.log(10000.0) / (channels // 2 - 1)
+    inv = torch.exp(-inc * torch.arange(channels // 2, dtype=torch.float32))
+    t = torch.arange(length, dtype=torch.float32)[:, None] * inv[None, :]
+    return torch.cat([t.sin(), t.cos()], dim=1)
+
+
+# ---------------------------------------------------------------------------- model
+def _attend(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
+            mask: torch.Tensor | None = None) -> torch.Tensor:
+    """q [B, Tq, d], k/v [B, Tk, d] -> [B, Tq, d]; scores in fp32."""
+    b, tq, d = q.shape
+    tk = k.shape[1]
+    hd = d // heads
+    qh = q.view(b, tq, heads, hd).transpose(1, 2)
+    kh = k.view(b, tk, heads, hd).transpose(1, 2)
+    vh = v.view(b, tk, heads, hd).transpose(1, 2)
+    s = torch.matmul(qh, kh.transpose(-1, -2)).float() * (hd ** -0.5)
+    if mask is not None:
+        s = s + mask
+    p = torch.softmax(s, dim=-1).to(q.dtype)
+    return torch.matmul(p, vh).transpose(1, 2).reshape(b, tq, d)
+
+
+class WhisperModel:
+    def __init__(self, cfg: WhisperConfig, dtype: torch.dtype, device: torch.device):
+        self.cfg = cfg
+        self.dtype = dtype
+        self.device = device
+        self.w: dict[str, torch.Tensor] = {}
+        self.filters = torch.from_numpy(mel_filterbank(cfg.num_mel_bins)).to(device)
+
+    # ------------------------------------------------------------------ weights
+    def _names(self) -> dict[str, tuple[int, ...]]:
+        c = self.cfg
+        d = c.d_model
+        shapes: dict[str, tuple[int, ...]] = {
+            "encoder.conv1.weight": (d, c.num_mel_bins, 3), "encoder.conv1.bias": (d,),
+            "encoder.conv2.weight": (d, d, 3), "encoder.conv2.bias": (d,),
+            "encoder.embed_positions.weight": (c.max_source_positions, d),
+            "encoder.layer_norm.weight": (d,), "encoder.layer_norm.bias": (d,),
+            "decoder.embed_tokens.weight": (c.vocab_size, d),
+            "decoder.embed_positions.weight": (c.max_target_positions, d),
+            "decoder.layer_norm.weight": (d,), "decoder.layer_norm.bias": (d,),
+        }
+
+        def attn(prefix):
+            for proj in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                shapes[f"{prefix}.{proj}.weight"] = (d, d)
+                if proj != "k_proj":
+                    shapes[f"{prefix}.{proj}.bias"] = (d,)
+
+        def block(prefix, ffn, cross):
+            attn(f"{prefix}.self_attn")
+            shapes[f"{prefix}.self_attn_layer_norm.weight"] = (d,)
+            shapes[f"{prefix}.self_attn_layer_norm.bias"] = (d,)
+            if cross:
+                attn(f"{prefix}.encoder_attn")
+                shapes[f"{prefix}.encoder_attn_layer_norm.weight"] = (d,)
+                shapes[f"{prefix}.encoder_attn_layer_norm.bias"] = (d,)
+            shapes[f"{prefix}.fc1.weight"] = (ffn, d)
+            shapes[f"{prefix}.fc1.bias"] = (ffn,)
+            shapes[f"{prefix}.fc2.weight"] = (d, ffn)
+            shapes[f"{prefix}.fc2.bias"] = (d,)
+            shapes[f"{prefix}.final_layer_norm.weight"] = (d,)
+            shapes[f"{prefix}.final_layer_norm.bias"] = (d,)
+
+        for i in range(c.encoder_layers):
+            block(f"encoder.layers.{i}", c.encoder_ffn_dim, False)
+        for i in range(c.decoder_layers):
+            block(f"decoder.layers.{i}", c.decoder_ffn_dim, True)
+        return shapes
+
+    def init_random(self, seed: int = 0) -> None:
+        g = torch.Generator().manual_seed(seed)
+        for name, shape in self._names().items():
+            if name == "encoder.embed_positions.weight":
+                t = _sinusoids(*shape)
+            elif "layer_norm.weight" in name:
+                t = torch.ones(shape)
+            elif name.endswith(".bias"):
+                t = torch.zeros(shape)
+            else:
+                t = torch.empty(shape).normal_(0.0, 0.02, generator=g)
+            self.w[name] = t.to(device=self.device, dtype=self.dtype)
+
+    def load_hf(self, ckpt_dir: Path) -> None:
+        """Read ``model.*`` tensors from the safetensors shards of a Hugging Face checkpoint."""
+        from safetensors import safe_open
+
+        want = self._names()
+        files = sorted(Path(ckpt_dir).glob("*.safetensors"))
+        if not files:
+            raise FileNotFoundError(f"no .safetensors files in {ckpt_dir}")
+        for fp in files:
+            with safe_open(str(fp), framework="pt") as f:
+                for key in f.keys():
+                    name = key[6:] if key.startswith("model.") else key
+                    if name not in want:
+                        continue
+                    t = f.get_tensor(key)
+                    if tuple(t.shape) != want[name]:
+                        raise ValueError(f"{key}: shape {tuple(t.shape)}, expected {want[name]}")
+                    self.w[name] = t.to(device=self.device, dtype=self.dtype)
+        if "encoder.embed_positions.weight" not in self.w:
+            self.w["encoder.embed_positions.weight"] = _sinusoids(
+                *want["encoder.embed_positions.weight"]).to(device=self.device, dtype=self.dtype)
+        missing = [n for n in want if n not in self.w]
+        if missing:
+            raise ValueError(f"checkpoint lacks {len(missing)} tensors, e.g. {missing[:3]}")
+
+    def weight_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.w.values())
+
+    # ------------------------------------------------------------------ blocks
+    def _ln(self, x, prefix):
+        return F.layer_norm(x, (x.shape[-1],), self.w[prefix + ".weight"], self.w[prefix + ".bias"], 1e-5)
+
+    def _lin(self, x, prefix):
+        return F.linear(x, self.w[prefix + ".weight"], self.w.get(prefix + ".bias"))
+
+    def _mlp(self, x, prefix):
+        return self._lin(F.gelu(self._lin(x, prefix + ".fc1")), prefix + ".fc2")
+
+    # ------------------------------------------------------------------ encoder
+    @torch.inference_mode()
+    def encode(self, mel: torch.Tensor) -> torch.Tensor:
+        """[B, n_mels, 3000] -> [B, 1500, d]."""
+        c, w = self.cfg, self.w
+        x = F.gelu(F.conv1d(mel.to(self.dtype), w["encoder.conv1.weight"], w["encoder.conv1.bias"], padding=1))
+        x = F.gelu(F.conv1d(x, w["encoder.conv2.weight"], w["encoder.conv2.bias"], stride=2, padding=1))
+        x = x.transpose(1, 2) + w["encoder.embed_positions.weight"][: x.shape[2]]
+        for i in range(c.encoder_layers):
+            p = f"encoder.layers.{i}"
+            h = self._ln(x, p + ".self_attn_layer_norm")
+            a = _attend(self._lin(h, p + ".self_attn.q_proj"), self._lin(h, p + ".self_attn.k_proj"),
+                        self._lin(h, p + ".self_attn.v_proj"), c.encoder_heads)
+            x = x + self._lin(a, p + ".self_attn.out_proj")
+            x = x + self._mlp(self._ln(x, p + ".final_layer_norm"), p)
+        return self._ln(x, "encoder.layer_norm")
+
+    @torch.inference_mode()
+    def cross_kv(self, enc: torch.Tensor) -> list[tuple[torch.Tensor, torch.Tensor]]:
+        """Per decoder layer K/V of the encoder output: computed once per window."""
+        return [(self._lin(enc, f"decoder.layers.{i}.encoder_attn.k_proj"),
+                 self._lin(enc, f"decoder.layers.{i}.encoder_attn.v_proj"))
+                for i in range(self.cfg.decoder_layers)]
+
+    # ------------------------------------------------------------------ decoder
+    @torch.inference_mode()
+    def decode(self, tokens: torch.Tensor, offset: int, cross: list, cache: list) -> torch.Tensor:
+        """Run ``tokens`` [B, T] at positions offset.. through the decoder; ``cache`` holds the
+        self-attention K/V of earlier positions per layer and is extended in place.
+        Returns logits of the last position [B, vocab] (fp32)."""
+        c, w = self.cfg, self.w
+        b, t = tokens.shape
+        x = F.embedding(tokens, w["decoder.embed_tokens.weight"]) + \
+            w["decoder.embed_positions.weight"][offset: offset + t]
+        mask = None
+        if t > 1:
+            mask = torch.full((t, offset + t), float("-inf"), device=x.device)
+            mask = torch.triu(mask, diagonal=offset + 1)
+        for i in range(c.decoder_layers):
+            p = f"decoder.layers.{i}"
+            h = self._ln(x, p + ".self_attn_layer_norm")
+            k_new = self._lin(h, p + ".self_attn.k_proj")
+            v_new = self._lin(h, p + ".self_attn.v_proj")
+            if cache[i] is None:
+                k_all, v_all = k_new, v_new
+            else:
+                k_all = torch.cat([cache[i][0], k_new], dim=1)
+                v_all = torch.cat([cache[i][1], v_new], dim=1)
+            cache[i] = (k_all, v_all)
+            a = _attend(self._lin(h, p + ".self_attn.q_proj"), k_all, v_all, c.decoder_heads, mask)
+            x = x + self._lin(a, p + ".self_attn.out_proj")
+            h = self._ln(x, p + ".encoder_attn_layer_norm")
+            a = _attend(self._lin(h, p + ".encoder_attn.q_proj"), cross[i][0], cross[i][1], c.decoder_heads)
+            x = x + self._lin(a, p + ".encoder_attn.out_proj")
+            x = x + self._mlp(self._ln(x, p + ".final_layer_norm"), p)
+        x = self._ln(x[:, -1], "decoder.layer_norm")
+        return F.linear(x, w["decoder.embed_tokens.weight"]).float()
+
+    # ------------------------------------------------------------------ generation
+    def prompt_ids(self, language_token: int | None, task: str = "transcribe") -> list[int]:
+        c = self.cfg
+        lang = c.first_language_token_id if language_token is None else language_token
+        task_id = c.translate_token_id if task == "translate" else c.transcribe_token_id
+        return [c.sot_token_id, lang, task_id, c.no_timestamps_token_id]
+
+    @torch.inference_mode()
+    def transcribe_windows(self, windows: torch.Tensor, prompts: list[list[int]],
+                           max_new_tokens: int | None = None, temperature: float = 0.0,
+                           generator: torch.Generator | None = None) -> list[list[int]]:
+        """Greedy (or sampled) decoding of a batch of 30 s windows [B, N_SAMPLES].  Prompts must
+        have equal length (they do: sot, language, task, no-timestamps).  Special tokens at or
+        above the end-of-text id other than end-of-text itself are never emitted."""
+        c = self.cfg
+        b = windows.shape[0]
+        mel = log_mel(windows.to(self.device), c.num_mel_bins, self.filters)
+        cross = self.cross_kv(self.encode(mel))
+        cache: list = [None] * c.decoder_layers
+        tokens = torch.tensor(prompts, dtype=torch.long, device=self.device)
+        limit = c.max_target_positions - tokens.shape[1]
+        steps = limit if max_new_tokens is None else min(limit, max_new_tokens)
+        done = torch.zeros(b, dtype=torch.bool, device=self.device)
+        out: list[list[int]] = [[] for _ in range(b)]
+        offset, feed = 0, tokens
+        ids = torch.arange(c.vocab_size, device=self.device)
+        lo = c.suppress_lo or c.eos_token_id + 1
+        hi = c.suppress_hi or c.vocab_size
+        suppress = (ids >= lo) & (ids < hi) & (ids != c.eos_token_id)
+        for step in range(steps):
+            logits = self.decode(feed, offset, cross, cache)
+            offset += feed.shape[1]
+            logits[:, suppress] = float("-inf")
+            if temperature > 0:
+                probs = torch.softmax(logits / temperature, dim=-1)
+                nxt = torch.multinomial(probs, 1, generator=generator).squeeze(1)
+            else:
+                nxt = logits.argmax(dim=-1)
+            nxt = torch.where(done, torch.full_like(nxt, c.eos_token_id), nxt)
+            done = done | (nxt == c.eos_token_id)
+            host = nxt.tolist()
+            for i, tkn in enumerate(host):
+                if tkn != c.eos_token_id:
+                    out[i].append(tkn)
+            if bool(done.all()):
+                break
+            feed = nxt[:, None]
+        return out
