@@ -28,9 +28,10 @@ def main():
     ap.add_argument("--chunk", type=int, default=8192)
     ap.add_argument("--no-chunked", action="store_true")
     ap.add_argument("--eager", action="store_true")
+    ap.add_argument("--max-num-seqs", type=int, default=64)
     args = ap.parse_args()
 
-    cfg = EngineConfig(model=args.model, max_model_len=32000, max_num_seqs=64,
+    cfg = EngineConfig(model=args.model, max_model_len=32000, max_num_seqs=args.max_num_seqs,
                        max_num_batched_tokens=args.chunk,
                        enable_chunked_prefill=not args.no_chunked, enforce_eager=args.eager)
     t0 = time.time()
@@ -48,7 +49,11 @@ def main():
     torch.cuda.synchronize()
 
     for b in [int(x) for x in args.batches.split(",")]:
-        sp = SamplingParams(max_tokens=args.decode_steps + 1, temperature=0, ignore_eos=True)
+        # early requests decode while later ones are still prefilled: give every request enough
+        # tokens to be alive through the whole prefill phase and the timed steps
+        prefill_steps = (b * args.ctx + args.chunk - 1) // args.chunk + b
+        sp = SamplingParams(max_tokens=args.decode_steps + 4 + prefill_steps, temperature=0,
+                            ignore_eos=True)
         reqs = [eng.add_request(prompt(args.ctx), SamplingParams(**sp.__dict__)) for _ in range(b)]
         torch.cuda.synchronize()
         t0 = time.time()
@@ -67,6 +72,8 @@ def main():
             n += 1
         torch.cuda.synchronize()
         t_dec = (time.time() - t0) / max(1, n)
+        for r in reqs:
+            eng.abort(r.request_id)
         while eng.has_work():
             eng.step()
         print(json.dumps({

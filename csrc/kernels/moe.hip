@@ -288,3 +288,182 @@ VPSA_EXPORT int vpsa_moe_gemv(const void* x, const void* w13, const void* w2, co
                      (uint16_t*)y, hidden, inter);
   return 0;
 }
+
+// ---------------------------------------------------------------------------------
+// Decode-batch expert MLP on the matrix cores: every expert's weights are streamed ONCE and
+// multiplied with all tokens routed to it (the GEMV kernels above re-read an expert per pair;
+// running all experts on all rows multiplies the FLOPs by E / top-k).  Works on the
+// expert-sorted pair list of moe_align (offsets / sorted_tok), so there is no host sync and
+// the launch shape does not depend on the routing: HIP-graph capturable.
+//
+// MFMA 16x16x32 bf16 with the weights as the A operand (16 weight rows x 32 reduction
+// elements: one 16-byte global load per lane, consumed straight from registers) and up to
+// TT tiles of 16 tokens as B operands (token rows are read through L2: they are tiny next to
+// the weights).  D: lane (c16, g) holds weight rows 4g..4g+3 of token column c16, so the
+// epilogue writes 4 consecutive bf16 per lane.
+//   gate_up: grid (I / 64, E); wave w of a block owns gate rows i0..i0+15 and the matching
+//            up rows, fuses silu(gate) * up, writes act[sorted row, i]
+//   down:    grid (H / 16, E); the block's 4 waves split the reduction (I) in four slices
+//            and combine through LDS, write y[sorted row, h]
+// Experts without tokens return at once; an expert with more than 16 * TT tokens loops
+// (its weights are then streamed once per 16 * TT tokens).
+// ---------------------------------------------------------------------------------
+#define MOE_KU 4  // reduction steps (of 32) whose loads are issued together
+
+template <int TT>
+__global__ __launch_bounds__(256) void moe_mfma_gate_up_kernel(
+    const uint16_t* __restrict__ x, const uint16_t* __restrict__ w13,
+    const int* __restrict__ offsets, const int* __restrict__ sorted_tok,
+    uint16_t* __restrict__ act, int hidden, int inter) {
+  const int e = blockIdx.y;
+  const int r0 = offsets[e];
+  const int n_e = offsets[e + 1] - r0;
+  if (n_e <= 0) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c16 = lane & 15, g = lane >> 4;
+  const int i0 = (blockIdx.x * 4 + wave) * 16;
+  const uint16_t* wg = w13 + ((long)e * 2 * inter + i0 + c16) * hidden + 8 * g;
+  const uint16_t* wu = wg + (long)inter * hidden;
+  for (int t0 = 0; t0 < n_e; t0 += 16 * TT) {
+    const int nt = min(TT, (n_e - t0 + 15) >> 4);
+    const uint16_t* xp[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const int j = min(t0 + tt * 16 + c16, n_e - 1);  // padded columns repeat the last token
+      xp[tt] = x + (long)sorted_tok[r0 + j] * hidden + 8 * g;
+    }
+    f32x4 accg[TT], accu[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) accg[tt] = accu[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < hidden; k += 32 * MOE_KU) {
+      u32x4 ag[MOE_KU], au[MOE_KU];
+#pragma unroll
+      for (int u = 0; u < MOE_KU; ++u) {
+        ag[u] = *reinterpret_cast<const u32x4*>(wg + k + 32 * u);
+        au[u] = *reinterpret_cast<const u32x4*>(wu + k + 32 * u);
+      }
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt)
+        if (tt < nt) {
+          u32x4 b[MOE_KU];
+#pragma unroll
+          for (int u = 0; u < MOE_KU; ++u) b[u] = *reinterpret_cast<const u32x4*>(xp[tt] + k + 32 * u);
+#pragma unroll
+          for (int u = 0; u < MOE_KU; ++u) {
+            accg[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, ag[u]), __builtin_bit_cast(bf16x8, b[u]), accg[tt], 0, 0, 0);
+            accu[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, au[u]), __builtin_bit_cast(bf16x8, b[u]), accu[tt], 0, 0, 0);
+          }
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const int j = t0 + tt * 16 + c16;
+      if (tt < nt && j < n_e) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gt = accg[tt][r];
+          v[r] = gt / (1.f + __expf(-gt)) * accu[tt][r];
+        }
+        u32x2 o;
+        o[0] = pack_bf16x2(v[0], v[1]);
+        o[1] = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<u32x2*>(act + (long)(r0 + j) * inter + i0 + 4 * g) = o;
+      }
+    }
+  }
+}
+
+template <int TT>
+__global__ __launch_bounds__(256) void moe_mfma_down_kernel(
+    const uint16_t* __restrict__ act, const uint16_t* __restrict__ w2,
+    const int* __restrict__ offsets, uint16_t* __restrict__ y, int hidden, int inter) {
+  __shared__ f32x4 red[4][TT][64];
+  const int e = blockIdx.y;
+  const int r0 = offsets[e];
+  const int n_e = offsets[e + 1] - r0;
+  if (n_e <= 0) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c16 = lane & 15, g = lane >> 4;
+  const int h0 = blockIdx.x * 16;
+  const int slice = inter >> 2;  // per wave; a multiple of 32 * MOE_KU (checked on the host)
+  const uint16_t* wp = w2 + ((long)e * hidden + h0 + c16) * inter + wave * slice + 8 * g;
+  for (int t0 = 0; t0 < n_e; t0 += 16 * TT) {
+    const int nt = min(TT, (n_e - t0 + 15) >> 4);
+    const uint16_t* ap[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const int j = min(t0 + tt * 16 + c16, n_e - 1);
+      ap[tt] = act + (long)(r0 + j) * inter + wave * slice + 8 * g;
+    }
+    f32x4 acc[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < slice; k += 32 * MOE_KU) {
+      u32x4 a[MOE_KU];
+#pragma unroll
+      for (int u = 0; u < MOE_KU; ++u) a[u] = *reinterpret_cast<const u32x4*>(wp + k + 32 * u);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt)
+        if (tt < nt) {
+          u32x4 b[MOE_KU];
+#pragma unroll
+          for (int u = 0; u < MOE_KU; ++u) b[u] = *reinterpret_cast<const u32x4*>(ap[tt] + k + 32 * u);
+#pragma unroll
+          for (int u = 0; u < MOE_KU; ++u)
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, a[u]), __builtin_bit_cast(bf16x8, b[u]), acc[tt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+      if (tt < nt) red[wave][tt][lane] = acc[tt];
+    __syncthreads();
+    // wave w finishes token tile w (TT <= 4)
+    if (wave < nt) {
+      const f32x4 s = red[0][wave][lane] + red[1][wave][lane] + red[2][wave][lane] + red[3][wave][lane];
+      const int j = t0 + wave * 16 + c16;
+      if (j < n_e) {
+        u32x2 o;
+        o[0] = pack_bf16x2(s[0], s[1]);
+        o[1] = pack_bf16x2(s[2], s[3]);
+        *reinterpret_cast<u32x2*>(y + (long)(r0 + j) * hidden + h0 + 4 * g) = o;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int TT>
+static void launch_moe_mfma(const void* x, const void* w13, const void* w2, const int* offsets,
+                            const int* sorted_tok, void* act, void* y, int n_experts, int hidden,
+                            int inter, hipStream_t stream) {
+  hipLaunchKernelGGL(moe_mfma_gate_up_kernel<TT>, dim3(inter / 64, n_experts), dim3(256), 0, stream,
+                     (const uint16_t*)x, (const uint16_t*)w13, offsets, sorted_tok, (uint16_t*)act,
+                     hidden, inter);
+  hipLaunchKernelGGL(moe_mfma_down_kernel<TT>, dim3(hidden / 16, n_experts), dim3(256), 0, stream,
+                     (const uint16_t*)act, (const uint16_t*)w2, offsets, (uint16_t*)y, hidden, inter);
+}
+
+// x [tokens, hidden]; w13 [E, 2*inter, hidden]; w2 [E, hidden, inter]; offsets [E+1] and
+// sorted_tok [tokens*topk] from vpsa_moe_align; act [tokens*topk, inter] and
+// y [tokens*topk, hidden] are workspaces in expert-sorted row order.
+VPSA_EXPORT int vpsa_moe_mfma(const void* x, const void* w13, const void* w2, const int* offsets,
+                              const int* sorted_tok, void* act, void* y, int tokens, int topk,
+                              int n_experts, int hidden, int inter, hipStream_t stream) {
+  if (tokens * topk <= 0) return 0;
+  if (n_experts > MAX_EXPERTS) return -1;
+  if (hidden % (32 * MOE_KU) != 0 || hidden % 16 != 0 || inter % 64 != 0 ||
+      (inter / 4) % (32 * MOE_KU) != 0)
+    return -1;
+  // an expert sees each token at most once: tokens bounds its row count
+  if (tokens <= 16)
+    launch_moe_mfma<1>(x, w13, w2, offsets, sorted_tok, act, y, n_experts, hidden, inter, stream);
+  else if (tokens <= 32)
+    launch_moe_mfma<2>(x, w13, w2, offsets, sorted_tok, act, y, n_experts, hidden, inter, stream);
+  else
+    launch_moe_mfma<4>(x, w13, w2, offsets, sorted_tok, act, y, n_experts, hidden, inter, stream);
+  return 0;
+}

@@ -248,3 +248,35 @@ def test_moe_small_batch_experts(t, hidden, inter):
     out = ops.moe_experts_small_batch(x, w13, w2, ids, w)
     exp = ref.moe_experts(x, w13, w2, ids, w)
     torch.testing.assert_close(out.float(), exp.float(), atol=3e-2, rtol=3e-2)
+
+
+@pytest.mark.parametrize("t,hidden,inter,skew", [
+    (1, 4096, 14336, False), (8, 512, 1024, False), (40, 512, 1024, False),
+    (100, 512, 1024, True), (256, 256, 512, False), (33, 4096, 14336, False)])
+def test_moe_grouped_mfma_experts(t, hidden, inter, skew):
+    """Expert-grouped matrix-core path against the per-pair fp32 definition; `skew` routes every
+    token to the same two experts so that one expert's rows exceed a single pass of token tiles."""
+    torch.manual_seed(19)
+    e, k = 8, 2
+    x = torch.randn(t, hidden, device=DEV).to(BF)
+    w13 = (torch.randn(e, 2 * inter, hidden, device=DEV) * 0.03).to(BF)
+    w2 = (torch.randn(e, hidden, inter, device=DEV) * 0.03).to(BF)
+    logits = torch.randn(t, e, device=DEV).to(BF)
+    if skew:
+        logits[:, 3] += 20.0
+        logits[:, 6] += 10.0
+    w, ids = ops.moe_topk_softmax(logits, k)
+    out = ops.moe_experts_grouped(x, w13, w2, ids, w).float()
+    # fp32 definition without intermediate rounding (the kernel keeps gate/up in fp32 through
+    # SiLU; only the activation and the per-pair output are rounded to bf16)
+    exp = torch.zeros((t, hidden), dtype=torch.float32, device=DEV)
+    xf = x.float()
+    for ex in range(e):
+        rows, slot = (ids == ex).nonzero(as_tuple=True)
+        if rows.numel() == 0:
+            continue
+        gu = xf[rows] @ w13[ex].float().t()
+        a = torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:]
+        exp.index_add_(0, rows, (a @ w2[ex].float().t()) * w[rows, slot].unsqueeze(1))
+    err = (out - exp).abs().max().item() / exp.abs().max().item()
+    assert err < 8e-3, err

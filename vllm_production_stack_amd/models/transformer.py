@@ -172,12 +172,19 @@ class TransformerModel:
         e, k = cfg.num_experts, cfg.num_experts_per_tok
         logits = F.linear(x, lw.router)
         w, ids = ops.moe_topk_softmax(logits, k)
+        if decode_only and t <= 2 and x.is_cuda:
+            # one or two tokens rarely share an expert: per-pair GEMV kernels, no sort
+            return ops.moe_experts_small_batch(x, lw.w13, lw.w2, ids, w)
+        if x.is_cuda and t <= ops.MOE_MFMA_MAX_TOKENS and ops.moe_mfma_supported(x.shape[1], lw.w2.shape[2]):
+            # Decode-sized batches: sort the (token, expert) pairs by expert and stream each
+            # routed expert's weights once against all of its tokens (matrix-core kernels,
+            # no host sync: HIP-graph capturable).
+            return ops.moe_experts_grouped(x, lw.w13, lw.w2, ids, w)
         if decode_only and t <= 16 and x.is_cuda:
-            # A handful of tokens: stream only the routed experts' weights (GEMV kernels).
             return ops.moe_experts_small_batch(x, lw.w13, lw.w2, ids, w)
         if decode_only or t <= 16:
-            # Small batches: every expert's weights are streamed anyway, so run all experts
-            # on all rows (no host sync: HIP-graph capturable) and mix with the routing matrix.
+            # Small batches on odd shapes / the CPU: run all experts on all rows (no host
+            # sync) and mix with the routing matrix.
             dense = torch.zeros((t, e), dtype=torch.float32, device=x.device)
             dense.scatter_(1, ids.long(), w)
             gu = torch.matmul(x.unsqueeze(0), lw.w13.transpose(1, 2))  # [E, T, 2I]
