@@ -268,6 +268,7 @@ class EngineConfig:
     kv_offload: KVOffloadConfig = field(default_factory=KVOffloadConfig)
     swap_space: float = 0.0
     enforce_eager: bool = False
+    capture_graphs_at_start: bool = True  # HIP graphs for all decode batch buckets at start-up
     seed: int = 0
     api_key: str | None = None
     disable_log_requests: bool = False

@@ -50,6 +50,12 @@ class LLMEngine:
         self.prof = {"steps": 0, "decode_only_steps": 0, "mixed_steps": 0, "t_schedule": 0.0,
                      "t_execute": 0.0, "t_post": 0.0, "rows": 0}
         self._init_kv_tiers()
+        if cfg.capture_graphs_at_start:
+            # decode graphs for every batch bucket now, not on the first step that needs one
+            t0 = time.time()
+            n = self.runner.capture_all_graphs()
+            if n:
+                log.info("captured %d decode graphs in %.1f s", n, time.time() - t0)
         log.info("engine ready: %d KV pages (%d tokens, %.1f GiB), max_model_len=%d",
                  self.runner.num_pages, self.runner.num_pages * PAGE,
                  self.runner.num_pages * self.runner.page_bytes / 2**30, self.max_model_len)

@@ -367,6 +367,17 @@ class ModelRunner:
             if b not in self._graphs and b <= self.cfg.max_num_seqs:
                 self._graphs[self._bucket(b)] = self._capture(self._bucket(b))
 
+    def capture_all_graphs(self) -> int:
+        """Capture the decode graph of every batch bucket up to ``max_num_seqs`` (largest first:
+        the shared graph memory pool is then sized once).  Returns the number captured."""
+        if not self.use_graphs:
+            return 0
+        todo = [b for b in _GRAPH_BUCKETS if b <= self._bucket(min(self.cfg.max_num_seqs, _GRAPH_BUCKETS[-1]))
+                and b not in self._graphs]
+        for b in sorted(todo, reverse=True):
+            self._graphs[b] = self._capture(b)
+        return len(todo)
+
     # ------------------------------------------------------------------ sleep / wake
     def sleep(self, level: int = 1) -> int:
         """Release HBM: weights to pinned host memory (level 1) or dropped (level 2); the KV
@@ -420,3 +431,5 @@ class ModelRunner:
         self._sleep_stash = []
         self.pool = torch.zeros(self._pool_shape, dtype=self.dtype, device=self.device)
         self.sleeping = False
+        if self.cfg.capture_graphs_at_start:
+            self.capture_all_graphs()
