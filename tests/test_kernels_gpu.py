@@ -280,3 +280,35 @@ def test_moe_grouped_mfma_experts(t, hidden, inter, skew):
         exp.index_add_(0, rows, (a @ w2[ex].float().t()) * w[rows, slot].unsqueeze(1))
     err = (out - exp).abs().max().item() / exp.abs().max().item()
     assert err < 8e-3, err
+
+
+@pytest.mark.parametrize("t,in_dim,outs,r_pad", [
+    (1, 4096, [4096, 1024, 1024], 32), (37, 512, [256], 32), (300, 1024, [512, 512], 64),
+    (40, 14336, [4096], 32)])
+def test_lora_shrink_expand_mixed_adapters(t, in_dim, outs, r_pad):
+    """Batched multi-adapter LoRA kernels against the fp32 definition: rows carry different
+    adapter slots (or none) in arbitrary order."""
+    torch.manual_seed(21)
+    n_slots = 4
+    g = torch.Generator().manual_seed(5)
+    slots = torch.randint(-1, n_slots, (t,), generator=g).to(torch.int32).to(DEV)
+    if t > 32:
+        slots[16:32] = 2  # a uniform tile next to mixed ones
+    x = torch.randn(t, in_dim, device=DEV).to(BF)
+    a = (torch.randn(n_slots, len(outs) * r_pad, in_dim, device=DEV) * 0.05).to(BF)
+    bs = [(torch.randn(n_slots, o, r_pad, device=DEV) * 0.05).to(BF) for o in outs]
+    y = torch.randn(t, sum(outs) + 64, device=DEV).to(BF)  # wider than the outputs: strided rows
+    y0 = y.clone()
+    h = ops.lora_shrink(x, a, slots, a.shape[1])
+    h_ref = ref.lora_shrink(x, a, slots)
+    has = slots >= 0
+    torch.testing.assert_close(h[has].float(), h_ref[has].float(), atol=2e-2, rtol=2e-2)
+    off = 0
+    y_ref = y0.clone()
+    ops.lora_expand(h, bs, slots, y, r_pad)
+    for sub, b in enumerate(bs):
+        ref.lora_expand(h, sub * r_pad, b, slots, y_ref, off)
+        off += b.shape[1]
+    torch.testing.assert_close(y.float(), y_ref.float(), atol=3e-2, rtol=2e-2)
+    assert torch.equal(y[~has], y0[~has])  # rows without an adapter are untouched
+    assert torch.equal(y[:, off:], y0[:, off:])

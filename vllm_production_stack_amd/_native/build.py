@@ -28,7 +28,8 @@ CXX = shutil.which("g++") or "g++"
 TARGETS = {
     "vpsa_kernels": (
         "hip",
-        ["kernels/elementwise.hip", "kernels/attention.hip", "kernels/kvcache.hip", "kernels/moe.hip"],
+        ["kernels/elementwise.hip", "kernels/attention.hip", "kernels/kvcache.hip", "kernels/moe.hip",
+         "kernels/lora.hip"],
         [],
     ),
     "vpsa_kvio": ("hip", ["kvio/kvio.cpp"], []),

@@ -195,7 +195,7 @@ class ModelRunner:
         rows = plan["logits_rows"]
         meta.logits_rows = self._to_dev(rows, torch.int64) if rows else None
         if plan.get("lora_slots") is not None:
-            meta.lora_slots = self._to_dev(plan["lora_slots"], torch.int64)
+            meta.lora_slots = self._to_dev(plan["lora_slots"], torch.int32)
         return self._to_dev(plan["ids"], torch.int64), meta
 
     def _run_plan(self, plan: dict):
@@ -236,7 +236,7 @@ class ModelRunner:
                 elif hasattr(ev, "wait"):
                     ev.wait()
                 s.req.load_event = None
-        if (self.use_graphs and not out.prefills and self.model.lora is None
+        if (self.use_graphs and not out.prefills
                 and all(s.samples for s in out.decodes)
                 and len(out.decodes) <= _GRAPH_BUCKETS[-1]):
             return self._execute_decode_graph(out.decodes)
@@ -291,10 +291,12 @@ class ModelRunner:
                 return b
         return n
 
-    def _capture(self, bsz: int) -> dict:
+    def _capture(self, bsz: int, with_lora: bool = False) -> dict:
         dev = self.device
         mp = self.max_pages_per_seq
         st = {
+            "lora": torch.full((bsz,), -1, dtype=torch.int32, device=dev),
+            "lora_version": self.model.lora.version if with_lora else 0,
             "ids": torch.zeros(bsz, dtype=torch.int64, device=dev),
             "pos": torch.zeros(bsz, dtype=torch.int32, device=dev),
             "slots": torch.full((bsz,), -1, dtype=torch.int64, device=dev),
@@ -307,7 +309,8 @@ class ModelRunner:
         ws_ml = torch.empty((bsz, self.model.n_q, splits, 2), dtype=torch.float32, device=dev)
         meta = BatchMeta(positions=st["pos"], slots=st["slots"], num_decode=bsz,
                          dec_block_tables=st["bt"], dec_ctx_lens=st["ctx"], dec_num_splits=splits,
-                         dec_ws_o=ws_o, dec_ws_ml=ws_ml, logits_rows=None)
+                         dec_ws_o=ws_o, dec_ws_ml=ws_ml, logits_rows=None,
+                         lora_slots=st["lora"] if with_lora else None)
 
         def run():
             hidden = self.model.forward(st["ids"], self.pool, meta)
@@ -333,12 +336,20 @@ class ModelRunner:
     def _execute_decode_graph(self, decodes: list[ScheduledSeq]):
         n = len(decodes)
         bsz = self._bucket(n)
-        st = self._graphs.get(bsz)
+        lora = self.model.lora
+        with_lora = lora is not None and any(s.req.lora_slot >= 0 for s in decodes)
+        # graphs with adapter kernels are keyed apart and follow the adapter set: which
+        # (projection, layer) pairs launch LoRA kernels is decided on the host at capture time
+        key = (bsz, True) if with_lora else bsz
+        st = self._graphs.get(key)
+        if st is not None and with_lora and st["lora_version"] != lora.version:
+            st = None
         if st is None:
             t0 = time.time()
-            st = self._capture(bsz)
-            self._graphs[bsz] = st
-            log.info("captured decode graph for batch %d in %.2fs", bsz, time.time() - t0)
+            st = self._capture(bsz, with_lora)
+            self._graphs[key] = st
+            log.info("captured decode graph for batch %d%s in %.2fs", bsz,
+                     " (LoRA)" if with_lora else "", time.time() - t0)
         mp = self.max_pages_per_seq
         ids, pos, slots, ctx = [0] * bsz, [0] * bsz, [-1] * bsz, [0] * bsz
         bt = torch.zeros((bsz, mp), dtype=torch.int32)
@@ -355,6 +366,9 @@ class ModelRunner:
         st["slots"].copy_(self._to_dev(slots, torch.int64), non_blocking=True)
         st["ctx"].copy_(self._to_dev(ctx, torch.int32), non_blocking=True)
         st["bt"].copy_(bt.pin_memory().to(self.device, non_blocking=True), non_blocking=True)
+        if with_lora:
+            ls = [s.req.lora_slot for s in decodes] + [-1] * (bsz - n)
+            st["lora"].copy_(self._to_dev(ls, torch.int32), non_blocking=True)
         st["graph"].replay()
         reqs = [s.req for s in decodes]
         toks, infos = self.sampler.sample(st["logits"], reqs, st["toks"])

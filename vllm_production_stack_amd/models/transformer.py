@@ -235,8 +235,9 @@ class TransformerModel:
             if cfg.num_experts > 0:
                 h = self._moe(x, lw, decode_only)
             else:
-                gu = F.linear(x, lw.w_gate_up)
-                h = F.linear(ops.silu_and_mul(gu), lw.w_down)
+                gu = self._lora("gate_up", gl, x, F.linear(x, lw.w_gate_up), meta)
+                act = ops.silu_and_mul(gu)
+                h = self._lora("down", gl, act, F.linear(act, lw.w_down), meta)
             h = tp_all_reduce(h)
         if not pp.is_last:
             pp_send(h, pp.next)

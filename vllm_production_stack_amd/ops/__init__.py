@@ -31,7 +31,7 @@ def _kernels():
             "vpsa_paged_prefill", "vpsa_set_prefill_variant", "vpsa_set_decode_variant", "vpsa_paged_decode", "vpsa_kv_gather_pages",
             "vpsa_kv_scatter_pages", "vpsa_cachegen_encode", "vpsa_cachegen_decode",
             "vpsa_moe_topk_softmax", "vpsa_moe_align", "vpsa_moe_permute", "vpsa_moe_combine",
-            "vpsa_moe_gemv", "vpsa_moe_mfma",
+            "vpsa_moe_gemv", "vpsa_moe_mfma", "vpsa_lora_shrink", "vpsa_lora_expand",
         ):
             getattr(lib, name).restype = c_int
         _lib = lib
@@ -391,3 +391,48 @@ def moe_experts_small_batch(x, w13, w2, ids, weights):
     _check(rc, "moe_gemv")
     pos = torch.arange(t * k, dtype=torch.int32, device=x.device)
     return moe_combine(y, weights, pos, t)
+
+
+# ---------------------------------------------------------------------------- LoRA
+def lora_shrink(x, a, slots, rank_total):
+    """h[t] = A[slots[t]] @ x[t] for rows with slots[t] >= 0 (other rows are left unwritten).
+
+    x [T, in] bf16, a [S, R, in] bf16 (R = stacked, padded ranks), slots [T] int32 -> h [T, R] bf16."""
+    t = x.shape[0]
+    if not x.is_cuda:
+        return reference.lora_shrink(x, a, slots)
+    _bf16_cuda(x, a)
+    assert a.is_contiguous() and a.shape[1] == rank_total and a.shape[2] == x.shape[1]
+    assert slots.dtype == torch.int32 and slots.numel() == t and x.stride(1) == 1
+    h = torch.empty((t, rank_total), dtype=x.dtype, device=x.device)
+    rc = _kernels().vpsa_lora_shrink(_p(x), c_long(x.stride(0)), _p(a), _p(slots), _p(h), c_int(t),
+                                     c_int(x.shape[1]), c_int(rank_total), c_int(a.shape[0]), _stream())
+    _check(rc, "lora_shrink")
+    return h
+
+
+def lora_expand(h, bs, slots, y, r_pad):
+    """For each sub-module i (the parts of a fused projection, side by side in y and in h):
+    y[t, off_i : off_i + out_i] += B_i[slots[t]] @ h[t, i * r_pad : (i + 1) * r_pad], slots[t] >= 0.
+
+    h [T, n * r_pad] bf16, bs: list of [S, out_i, r_pad] bf16 (adapter scale folded in),
+    y [T, >= sum(out_i)] bf16, updated in place by one launch."""
+    if not h.is_cuda:
+        off = 0
+        for i, b in enumerate(bs):
+            reference.lora_expand(h, i * r_pad, b, slots, y, off)
+            off += b.shape[1]
+        return y
+    _bf16_cuda(h, y, *bs)
+    assert h.is_contiguous() and y.stride(1) == 1 and 1 <= len(bs) <= 3
+    n = len(bs)
+    outs = [b.shape[1] for b in bs]
+    assert all(b.is_contiguous() and b.shape[2] == r_pad for b in bs) and sum(outs) <= y.shape[1]
+    y_offs = [sum(outs[:i]) for i in range(n)]
+    ptrs = (c_void_p * n)(*[b.data_ptr() for b in bs])
+    rc = _kernels().vpsa_lora_expand(_p(h), c_int(h.stride(0)), ptrs, (c_int * n)(*outs),
+                                     (c_int * n)(*y_offs), (c_int * n)(*[i * r_pad for i in range(n)]),
+                                     c_int(n), _p(slots), _p(y), c_long(y.stride(0)), c_int(h.shape[0]),
+                                     c_int(r_pad), c_int(bs[0].shape[0]), _stream())
+    _check(rc, "lora_expand")
+    return y

@@ -195,3 +195,25 @@ def moe_experts(x, w13, w2, ids, weights):
             a = (torch.nn.functional.silu(gu[:inter]) * gu[inter:]).to(x.dtype).float()
             out[ti] += float(weights[ti, ki]) * (w2[e].float() @ a).to(x.dtype).float()
     return out.to(x.dtype)
+
+
+def lora_shrink(x, a, slots):
+    """h[t] = A[slots[t]] @ x[t]; rows without an adapter (slot < 0) give zeros."""
+    h = torch.zeros((x.shape[0], a.shape[1]), dtype=x.dtype, device=x.device)
+    for s in torch.unique(slots).tolist():
+        if s < 0:
+            continue
+        rows = (slots == s).nonzero(as_tuple=True)[0]
+        h[rows] = (x[rows].float() @ a[s].float().t()).to(x.dtype)
+    return h
+
+
+def lora_expand(h, h_off, b, slots, y, y_off):
+    out_dim, r_pad = b.shape[1], b.shape[2]
+    for s in torch.unique(slots).tolist():
+        if s < 0:
+            continue
+        rows = (slots == s).nonzero(as_tuple=True)[0]
+        delta = h[rows, h_off:h_off + r_pad].float() @ b[s].float().t()
+        y[rows, y_off:y_off + out_dim] = (y[rows, y_off:y_off + out_dim].float() + delta).to(y.dtype)
+    return y
