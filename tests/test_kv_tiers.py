@@ -131,6 +131,7 @@ def test_remote_cache_shared_between_engines(serde):
         e1.shutdown()
         e2.shutdown()
     finally:
+        asyncio.run_coroutine_threadsafe(srv.stop(), loop).result(10)
         loop.call_soon_threadsafe(loop.stop)
 
 
@@ -191,4 +192,5 @@ def test_controller_reporting_and_pd_push():
     try:
         asyncio.run(go())
     finally:
+        asyncio.run_coroutine_threadsafe(runner.cleanup(), loop).result(10)
         loop.call_soon_threadsafe(loop.stop)

@@ -317,3 +317,55 @@ def test_pii_regex_analyzer():
     assert r.types == {PIIType.EMAIL, PIIType.PHONE, PIIType.SSN, PIIType.CREDIT_CARD, PIIType.IP_ADDRESS}
     assert not a.analyze("the quick brown fox 1234 5678").has_pii
     assert not a.analyze("card 4111 1111 1111 1112").has_pii  # Luhn fails
+
+
+def test_departed_engines_are_forgotten():
+    """When an engine leaves service discovery the scraper reports it once, and the router drops
+    its request statistics and its ownership of prefix-trie nodes."""
+    import asyncio
+
+    from vllm_production_stack_amd.router.routing import PrefixAwareRouter
+    from vllm_production_stack_amd.router.stats import EngineStatsScraper, RequestStatsMonitor
+
+    class EP:
+        def __init__(self, url):
+            self.url = url
+
+    class SD:
+        def __init__(self):
+            self.eps = [EP("http://a:1"), EP("http://b:1")]
+
+        def get_endpoint_info(self):
+            return self.eps
+
+    sd = SD()
+    scraper = EngineStatsScraper(1.0, lambda: sd)
+
+    async def no_scrape(session, url):
+        return None
+
+    scraper._scrape_one = no_scrape
+    mon = RequestStatsMonitor(10.0)
+    router = PrefixAwareRouter()
+    gone_log = []
+
+    def gone(urls):
+        gone_log.append(urls)
+        for u in urls:
+            mon.forget_engine(u)
+            router.forget_endpoint(u)
+
+    scraper.on_engines_gone = gone
+    prompt = "x" * 1000
+    for ep in sd.eps:
+        mon.on_new_request(ep.url, "r-" + ep.url, 1.0)
+        router.hashtrie.insert(prompt, ep.url)
+    asyncio.run(scraper.scrape_once(None))
+    assert gone_log == []
+    sd.eps = sd.eps[:1]
+    asyncio.run(scraper.scrape_once(None))
+    asyncio.run(scraper.scrape_once(None))
+    assert gone_log == [["http://b:1"]]
+    assert set(mon.get_request_stats(2.0)) == {"http://a:1"}
+    _, matched = router.hashtrie.longest_prefix_match(prompt, {"http://a:1", "http://b:1"})
+    assert matched == {"http://a:1"}

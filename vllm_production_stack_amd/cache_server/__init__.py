@@ -64,8 +64,11 @@ class CacheServer:
         self.host, self.port = host, port
         self.store = LRUStore(max_bytes)
         self._server: asyncio.AbstractServer | None = None
+        self._conns: set[asyncio.Task] = set()
 
     async def _handle(self, reader: asyncio.StreamReader, writer: asyncio.StreamWriter) -> None:
+        task = asyncio.current_task()
+        self._conns.add(task)
         try:
             while True:
                 try:
@@ -97,9 +100,10 @@ class CacheServer:
                     status = ST_ERR
                 writer.write(struct.pack("<BQ", status, len(out)) + out)
                 await writer.drain()
-        except (ConnectionResetError, BrokenPipeError):
+        except (ConnectionResetError, BrokenPipeError, asyncio.CancelledError):
             pass
         finally:
+            self._conns.discard(task)
             writer.close()
 
     async def start(self) -> "CacheServer":
@@ -112,6 +116,12 @@ class CacheServer:
         if self._server:
             self._server.close()
             await self._server.wait_closed()
+        # wait_closed() does not cover connections that are already open: end their handlers
+        conns = list(self._conns)
+        for t in conns:
+            t.cancel()
+        if conns:
+            await asyncio.gather(*conns, return_exceptions=True)
 
 
 def main(argv: list[str] | None = None) -> None:

@@ -146,11 +146,6 @@ class BlockManager:
                 else:
                     self.free_ids.append(p)
 
-    def touch(self, pages: Iterable[int]) -> None:
-        for p in pages:
-            if p in self.evictable:
-                self.evictable.move_to_end(p)
-
     def reset_prefix_cache(self) -> int:
         """Drop every unreferenced cached page (used by /sleep and tests)."""
         n = 0

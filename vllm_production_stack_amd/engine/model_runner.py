@@ -271,18 +271,10 @@ class ModelRunner:
                     self._sleep_local(msg[1])
                 elif kind == "wake":
                     self._wake_local()
-                elif kind == "call":
-                    getattr(self, msg[1])(*msg[2])
 
     def stop_workers(self) -> None:
         if self.distributed and self.replica.is_driver:
             replica_broadcast(("stop",))
-
-    def replica_call(self, method: str, *args):
-        """Run ``self.<method>(*args)`` on every rank of the replica (driver side)."""
-        if self.distributed:
-            replica_broadcast(("call", method, args))
-        return getattr(self, method)(*args)
 
     # ------------------------------------------------------------------ HIP-graph decode
     def _bucket(self, n: int) -> int:
@@ -373,13 +365,6 @@ class ModelRunner:
         reqs = [s.req for s in decodes]
         toks, infos = self.sampler.sample(st["logits"], reqs, st["toks"])
         return list(zip(decodes, toks, infos))
-
-    def warmup(self, batch_sizes: list[int] | None = None) -> None:
-        if not self.use_graphs:
-            return
-        for b in batch_sizes or [1]:
-            if b not in self._graphs and b <= self.cfg.max_num_seqs:
-                self._graphs[self._bucket(b)] = self._capture(self._bucket(b))
 
     def capture_all_graphs(self) -> int:
         """Capture the decode graph of every batch bucket up to ``max_num_seqs`` (largest first:

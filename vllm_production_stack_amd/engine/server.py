@@ -12,7 +12,6 @@ from __future__ import annotations
 import asyncio
 import json
 import logging
-import math
 import time
 import uuid
 
@@ -557,10 +556,6 @@ class EngineServer:
         (engine/speech.py), which `serve` starts for Whisper-class models."""
         return _err(501, "this replica does not serve a transcription model; start one with "
                          "`serve openai/whisper-small --task transcription`", "NotImplementedError")
-
-
-def sanitize_float(x: float) -> float:
-    return 0.0 if (math.isnan(x) or math.isinf(x)) else x
 
 
 async def serve(aengine: AsyncLLMEngine, host: str, port: int) -> web.AppRunner:

@@ -37,7 +37,3 @@ def init_parallel_from_env(tp_size: int, pp_size: int = 1):
         dist.init_process_group(backend=backend, init_method="env://")
     init_replica_parallel(tp_size, pp_size)
     return get_tp()
-
-
-def init_tp_from_env(tp_size: int):
-    return init_parallel_from_env(tp_size, 1)

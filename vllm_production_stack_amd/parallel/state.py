@@ -116,26 +116,6 @@ def reset_parallel_state() -> None:
     set_replica(ReplicaGroup())
 
 
-def init_tp(tp_size: int, ranks: list[int] | None = None, backend: str | None = None) -> TPGroup:
-    """Create a tensor-parallel group from the default process group.
-
-    ``ranks`` are global ranks of this replica's group (default: all ranks)."""
-    if tp_size <= 1:
-        set_tp(TPGroup())
-        return _TP
-    if not dist.is_initialized():
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-        dist.init_process_group(backend=backend, init_method="env://")
-    world = dist.get_world_size()
-    ranks = ranks or list(range(world))
-    assert len(ranks) == tp_size, (ranks, tp_size)
-    group = dist.new_group(ranks=ranks)
-    cpu_group = dist.new_group(ranks=ranks, backend="gloo")
-    set_tp(TPGroup(rank=ranks.index(dist.get_rank()), size=tp_size, group=group, cpu_group=cpu_group))
-    set_replica(ReplicaGroup(rank=_TP.rank, size=tp_size, cpu_group=cpu_group, driver=ranks[0]))
-    return _TP
-
-
 def init_replica_parallel(tp_size: int, pp_size: int = 1) -> None:
     """Carve the default process group into replicas of ``pp_size x tp_size`` ranks and record
     this process's tensor-parallel group, pipeline neighbours and replica control group.
@@ -202,17 +182,6 @@ def pp_recv(shape, dtype: torch.dtype, device: torch.device, src: int) -> torch.
     t = torch.empty(shape, dtype=dtype, device=device)
     dist.recv(t, src=src)
     return t
-
-
-def broadcast_object(obj, src: int = 0):
-    """Control-plane broadcast from the tensor-parallel group's first rank (gloo)."""
-    tp = _TP
-    if tp.size == 1:
-        return obj
-    box = [obj]
-    src_global = dist.get_global_rank(tp.cpu_group, src)
-    dist.broadcast_object_list(box, src=src_global, group=tp.cpu_group)
-    return box[0]
 
 
 def replica_broadcast(obj):

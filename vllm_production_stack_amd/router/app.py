@@ -450,6 +450,16 @@ async def initialize_all(state: RouterState) -> None:
     state.engine_stats_scraper = EngineStatsScraper(
         args.engine_stats_interval, lambda: state.service_discovery,
         os.environ.get("VLLM_API_KEY") or None)
+
+    def engines_gone(urls: list[str]) -> None:
+        for url in urls:
+            state.request_stats_monitor.forget_engine(url)
+            forget = getattr(state.router, "forget_endpoint", None)
+            if forget is not None:
+                forget(url)
+        logger.info("dropped router state of departed engines: %s", ", ".join(urls))
+
+    state.engine_stats_scraper.on_engines_gone = engines_gone
     state.rewriter = get_request_rewriter(args.request_rewriter)
     await apply_dynamic_config(state, DynamicRouterConfig.from_args(args))
     await state.engine_stats_scraper.start()

@@ -66,6 +66,10 @@ class EngineStatsScraper:
         self.api_key = api_key
         self.engine_stats: dict[str, EngineStats] = {}
         self._task: asyncio.Task | None = None
+        self._known_urls: set[str] = set()
+        # called with the URLs that left service discovery since the previous scrape, so that
+        # per-engine router state (request statistics, prefix-trie ownership) does not outlive them
+        self.on_engines_gone = None
 
     async def start(self) -> None:
         self._task = asyncio.create_task(self._loop())
@@ -97,6 +101,10 @@ class EngineStatsScraper:
         res = await asyncio.gather(*[self._scrape_one(session, u) for u in urls])
         # replace wholesale: engines that disappeared from discovery are dropped
         self.engine_stats = {u: s for u, s in zip(urls, res) if s is not None}
+        gone = self._known_urls - set(urls)
+        self._known_urls = set(urls)
+        if gone and self.on_engines_gone is not None:
+            self.on_engines_gone(sorted(gone))
 
     async def _loop(self) -> None:
         async with aiohttp.ClientSession() as session:
