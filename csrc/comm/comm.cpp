@@ -18,10 +18,20 @@
 
 #define API extern "C" __attribute__((visibility("default")))
 
+// One process drives one GPU; the HIP current device is per thread (0 in a fresh thread).
+// comm_bind_device records the process's device and every entry point that touches a stream
+// or device memory moves its calling thread onto it first.
+static int g_device = -1;
+static inline void bind_thread() {
+  if (g_device >= 0) (void)hipSetDevice(g_device);
+}
+API void comm_bind_device(int device) { g_device = device; }
+
 // ---------------------------------------------------------------- hipIpc
 API int comm_ipc_handle_size() { return (int)sizeof(hipIpcMemHandle_t); }
 
 API int comm_ipc_export(void* dev_ptr, void* handle_out) {
+  bind_thread();
   hipIpcMemHandle_t h;
   hipError_t e = hipIpcGetMemHandle(&h, dev_ptr);
   if (e != hipSuccess) return (int)e;
@@ -30,6 +40,7 @@ API int comm_ipc_export(void* dev_ptr, void* handle_out) {
 }
 
 API void* comm_ipc_open(const void* handle) {
+  bind_thread();
   hipIpcMemHandle_t h;
   memcpy(&h, handle, sizeof(h));
   void* p = nullptr;
@@ -50,6 +61,7 @@ API int comm_enable_peer(int dev, int peer) {
 // Copy n pages from the local pool into a mapped peer pool on `stream`.
 API int comm_push_pages(const void* src_base, void* dst_base, size_t page_bytes,
                         const int64_t* src_pages, const int64_t* dst_pages, int n, void* stream) {
+  bind_thread();
   for (int i = 0; i < n; ++i) {
     const char* s = (const char*)src_base + (size_t)src_pages[i] * page_bytes;
     char* d = (char*)dst_base + (size_t)dst_pages[i] * page_bytes;
@@ -75,6 +87,7 @@ API void* comm_rccl_init(const void* id_bytes, int nranks, int rank, int device)
   ncclUniqueId id;
   memcpy(&id, id_bytes, sizeof(id));
   if (hipSetDevice(device) != hipSuccess) return nullptr;
+  g_device = device;
   ncclComm_t c = nullptr;
   if (ncclCommInitRank(&c, nranks, id, rank) != ncclSuccess) return nullptr;
   return c;
@@ -84,6 +97,7 @@ API int comm_rccl_destroy(void* c) { return (int)ncclCommDestroy((ncclComm_t)c);
 
 API int comm_rccl_send_pages(void* c, const void* base, size_t page_bytes, const int64_t* pages, int n,
                              int peer, void* stream) {
+  bind_thread();
   ncclGroupStart();
   for (int i = 0; i < n; ++i) {
     ncclResult_t r = ncclSend((const char*)base + (size_t)pages[i] * page_bytes, page_bytes, ncclChar,
@@ -98,6 +112,7 @@ API int comm_rccl_send_pages(void* c, const void* base, size_t page_bytes, const
 
 API int comm_rccl_recv_pages(void* c, void* base, size_t page_bytes, const int64_t* pages, int n,
                              int peer, void* stream) {
+  bind_thread();
   ncclGroupStart();
   for (int i = 0; i < n; ++i) {
     ncclResult_t r = ncclRecv((char*)base + (size_t)pages[i] * page_bytes, page_bytes, ncclChar, peer,

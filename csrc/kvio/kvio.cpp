@@ -43,6 +43,14 @@ struct Pool {
   int device = 0;
 };
 
+// One process drives one GPU.  The HIP current device is per thread (0 in a fresh thread), and
+// events, streams and async copies follow it: every entry point moves its calling thread to the
+// device the pool was created on.
+int g_device = -1;
+inline void bind_thread() {
+  if (g_device >= 0) (void)hipSetDevice(g_device);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- pinned pool
@@ -50,6 +58,7 @@ API void* kvio_pool_create(int device, size_t slot_bytes, size_t n_slots) {
   if (slot_bytes == 0 || n_slots == 0) return nullptr;
   Pool* p = new Pool();
   p->device = device;
+  g_device = device;
   p->slot_bytes = slot_bytes;
   p->n_slots = n_slots;
   if (hipSetDevice(device) != hipSuccess) {
@@ -136,6 +145,7 @@ API void* kvio_pool_stream(void* h) { return static_cast<Pool*>(h)->stream; }
 // on the compute stream after the producing kernels; the returned event (created here, owned
 // by the caller -> kvio_event_destroy) fires when the batch of copies has landed.
 API void* kvio_event_create() {
+  bind_thread();
   hipEvent_t e;
   if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
   return e;
@@ -144,17 +154,20 @@ API void kvio_event_destroy(void* e) {
   if (e) hipEventDestroy((hipEvent_t)e);
 }
 API int kvio_event_record(void* e, void* stream) {
+  bind_thread();
   return (int)hipEventRecord((hipEvent_t)e, (hipStream_t)stream);
 }
 API int kvio_event_query(void* e) { return hipEventQuery((hipEvent_t)e) == hipSuccess ? 1 : 0; }
 API int kvio_event_sync(void* e) { return (int)hipEventSynchronize((hipEvent_t)e); }
 API int kvio_stream_wait_event(void* stream, void* e) {
+  bind_thread();
   return (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)e, 0);
 }
 
 // device pages -> pinned slots.  dev_base + page_ids[i] * page_bytes is the source.
 API int kvio_offload_pages(void* h, const void* dev_base, size_t page_bytes, const int64_t* page_ids,
                            const int64_t* slots, int n, void* wait_event, void* done_event) {
+  bind_thread();
   Pool* p = static_cast<Pool*>(h);
   if (page_bytes > p->slot_bytes) return -1;
   if (wait_event && hipStreamWaitEvent(p->stream, (hipEvent_t)wait_event, 0) != hipSuccess) return -2;
@@ -170,6 +183,7 @@ API int kvio_offload_pages(void* h, const void* dev_base, size_t page_bytes, con
 // pinned slots -> device pages.
 API int kvio_load_pages(void* h, void* dev_base, size_t page_bytes, const int64_t* page_ids,
                         const int64_t* slots, int n, void* wait_event, void* done_event) {
+  bind_thread();
   Pool* p = static_cast<Pool*>(h);
   if (page_bytes > p->slot_bytes) return -1;
   if (wait_event && hipStreamWaitEvent(p->stream, (hipEvent_t)wait_event, 0) != hipSuccess) return -2;

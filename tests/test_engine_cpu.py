@@ -149,3 +149,33 @@ def test_context_limit_is_enforced():
     eng = make_engine()
     with pytest.raises(ValueError):
         eng.add_request(list(range(16, 16 + 1024)), SamplingParams())
+
+
+def test_kernel_launches_move_the_calling_thread_to_the_bound_gpu(monkeypatch):
+    """The HIP current device is per thread and starts at 0: a launch from a fresh thread of a
+    process bound to GPU 3 must select GPU 3 first (streams and kernel lookups follow it)."""
+    import threading
+
+    import torch
+
+    from vllm_production_stack_amd import ops
+
+    state = threading.local()
+    calls = []
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: getattr(state, "dev", 0))
+
+    def set_device(d):
+        state.dev = int(d)
+        calls.append((threading.current_thread().name, int(d)))
+
+    monkeypatch.setattr(torch.cuda, "set_device", set_device)
+    ops.bind_device(3)
+    try:
+        ops.ensure_device()
+        ops.ensure_device()  # already there: no second switch
+        t = threading.Thread(target=ops.ensure_device, name="fresh")
+        t.start()
+        t.join()
+    finally:
+        ops.bind_device(None)
+    assert calls == [(threading.current_thread().name, 3), ("fresh", 3)]

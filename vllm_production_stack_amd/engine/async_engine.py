@@ -56,6 +56,13 @@ class AsyncLLMEngine:
 
     def _run(self) -> None:
         eng = self.engine
+        dev = getattr(eng, "device", None)
+        if dev is not None and dev.type == "cuda":
+            # the HIP current device is per thread and starts at 0: without this, streams, graph
+            # captures and kernel launches of this thread would land on GPU 0 on every rank
+            import torch
+
+            torch.cuda.set_device(dev)
         while not self._stop:
             try:
                 while self._inbox:

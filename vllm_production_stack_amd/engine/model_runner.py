@@ -48,6 +48,7 @@ class ModelRunner:
         self.max_model_len = cfg.max_model_len or min(model_cfg.max_position_embeddings, 32768)
         if device.type == "cuda":
             torch.cuda.set_device(device)
+            ops.bind_device(device.index if device.index is not None else torch.cuda.current_device())
         t0 = time.time()
         self.model = build_model(model_cfg, self.dtype, device, self.max_model_len, ckpt_dir,
                                  cfg.seed, cfg.load_format)
@@ -232,10 +233,12 @@ class ModelRunner:
             ev = s.req.load_event
             if ev is not None:
                 if self.device.type == "cuda" and hasattr(ev, "record"):
-                    torch.cuda.current_stream().wait_event(ev)
+                    torch.cuda.current_stream(self.device).wait_event(ev)
                 elif hasattr(ev, "wait"):
                     ev.wait()
                 s.req.load_event = None
+        if self.device.type == "cuda":
+            ops.ensure_device()  # the calling thread may never have selected this process's GPU
         if (self.use_graphs and not out.prefills
                 and all(s.samples for s in out.decodes)
                 and len(out.decodes) <= _GRAPH_BUCKETS[-1]):
@@ -311,10 +314,10 @@ class ModelRunner:
 
         # warm up on a side stream (library workspaces, lazy inits), then capture
         s = torch.cuda.Stream(device=dev)
-        s.wait_stream(torch.cuda.current_stream())
+        s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
             run()
-        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=self._graph_pool):

@@ -108,6 +108,8 @@ class SpeechEngine:
 
     # ------------------------------------------------------------------ worker
     def _loop(self) -> None:
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)  # per-thread setting; a new thread starts on GPU 0
         while True:
             first = self._q.get()
             if first is None:

@@ -138,7 +138,7 @@ class HostKVPool:
         wait = None
         if self.gpu and compute_event is None:
             wait = _Event(self.lib)
-            self.lib.kvio_event_record(wait.h, c_void_p(torch.cuda.current_stream().cuda_stream))
+            self.lib.kvio_event_record(wait.h, c_void_p(torch.cuda.current_stream(self.pool.device).cuda_stream))
         pos = 0
         while pos < len(todo):
             n = min(len(todo) - pos, len(self.free_slots)) or 1
@@ -177,7 +177,7 @@ class HostKVPool:
         done = _Event(self.lib)
         # the target pages may still be read by kernels already queued on the compute stream
         wait = _Event(self.lib)
-        self.lib.kvio_event_record(wait.h, c_void_p(torch.cuda.current_stream().cuda_stream))
+        self.lib.kvio_event_record(wait.h, c_void_p(torch.cuda.current_stream(self.pool.device).cuda_stream))
         rc = self.lib.kvio_load_pages(self.h, c_void_p(self.pool.data_ptr()), self.page_bytes, pages,
                                       sl, n, wait.h, done.h)
         if rc != 0:
@@ -188,7 +188,7 @@ class HostKVPool:
     def make_compute_wait(self, ev) -> None:
         """Make the current compute stream wait for a copy-engine event (GPU-side fence)."""
         if ev is not None and self.gpu:
-            self.lib.kvio_stream_wait_event(c_void_p(torch.cuda.current_stream().cuda_stream), ev.h)
+            self.lib.kvio_stream_wait_event(c_void_p(torch.cuda.current_stream(self.pool.device).cuda_stream), ev.h)
 
 
 class DiskKVStore:

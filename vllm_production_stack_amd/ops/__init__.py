@@ -54,7 +54,25 @@ def set_decode_variant(v: int) -> int:
     return int(_kernels().vpsa_set_decode_variant(c_int(v)))
 
 
+_DEVICE: int | None = None
+
+
+def bind_device(index: int | None) -> None:
+    """One process drives one GPU.  The HIP current device is a per-thread setting that starts
+    at 0 in every new thread, and both ``torch.cuda.current_stream()`` and the kernel launches
+    of the native library follow it: record the process's device here and every launch from
+    any thread (engine loop, executor threads) first moves its thread onto that device."""
+    global _DEVICE
+    _DEVICE = index
+
+
+def ensure_device() -> None:
+    if _DEVICE is not None and torch.cuda.current_device() != _DEVICE:
+        torch.cuda.set_device(_DEVICE)
+
+
 def _stream():
+    ensure_device()
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -76,6 +76,13 @@ def comm():
         for fn in (lib.comm_rccl_send_pages, lib.comm_rccl_recv_pages):
             fn.restype = c_int
             fn.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_void_p]
+        lib.comm_bind_device.argtypes = [c_int]
+        if torch.cuda.is_available():
+            # this process's GPU; the library moves every calling thread onto it
+            from .. import ops
+
+            ops.ensure_device()
+            lib.comm_bind_device(c_int(torch.cuda.current_device()))
         _comm = lib
     return _comm
 
@@ -169,7 +176,7 @@ def _push_ipc(pool, target, handle_hex, pool_offset, page_bytes, src_pages, dst_
     sp = (ctypes.c_int64 * n)(*src_pages)
     dp = (ctypes.c_int64 * n)(*dst_pages)
     stream = torch.cuda.Stream(device=pool.device)
-    stream.wait_stream(torch.cuda.current_stream())
+    stream.wait_stream(torch.cuda.current_stream(pool.device))
     rc = lib.comm_push_pages(c_void_p(pool.data_ptr()), c_void_p(ent[0] + pool_offset), page_bytes,
                              sp, dp, n, c_void_p(stream.cuda_stream))
     if rc != 0:
@@ -210,7 +217,7 @@ def _push_rccl(pool, target, page_bytes, src_pages, dst_pages) -> None:
     _post(target + "/kv/rccl_recv", {"comm": key, "pages": dst_pages, "page_bytes": page_bytes})
     sp = (ctypes.c_int64 * n)(*src_pages)
     stream = torch.cuda.Stream(device=pool.device)
-    stream.wait_stream(torch.cuda.current_stream())
+    stream.wait_stream(torch.cuda.current_stream(pool.device))
     rc = lib.comm_rccl_send_pages(c_void_p(c), c_void_p(pool.data_ptr()), page_bytes, sp, n, 1,
                                   c_void_p(stream.cuda_stream))
     if rc != 0:
@@ -266,7 +273,7 @@ class KVReceiver:
         c = self._rccl[key]
         if self._rccl_stream is None:
             self._rccl_stream = torch.cuda.Stream(device=pool.device)
-        self._rccl_stream.wait_stream(torch.cuda.current_stream())
+        self._rccl_stream.wait_stream(torch.cuda.current_stream(pool.device))
         n = len(pages)
         dp = (ctypes.c_int64 * n)(*pages)
         rc = comm().comm_rccl_recv_pages(c_void_p(c), c_void_p(pool.data_ptr()), page_bytes, dp, n, 0,
@@ -319,7 +326,7 @@ def local_push(src_engine, receiver: "KVReceiver", prompt_ids: list[int]) -> int
             sp = (ctypes.c_int64 * n)(*src)
             dp = (ctypes.c_int64 * n)(*dst)
             stream = torch.cuda.Stream(device=spool.device)
-            stream.wait_stream(torch.cuda.current_stream())
+            stream.wait_stream(torch.cuda.current_stream(spool.device))
             rc = comm().comm_push_pages(c_void_p(spool.data_ptr()), c_void_p(dpool.data_ptr()),
                                         page_bytes, sp, dp, n, c_void_p(stream.cuda_stream))
             if rc != 0:
