@@ -140,12 +140,86 @@ def ttft(ctx=21000):
             "host_tier_loads": eng.connector.host.loads, "host_tier_stores": eng.connector.host.stores}
 
 
+def remote(ctx=21000, serde="naive"):
+    """Shared remote cache (lm://): raw put/get throughput of 8 MiB pages over loopback, and the
+    TTFT of a 21k-token prompt whose KV is only in the cache server (the replica's own HBM
+    prefix cache is dropped first) against recomputing it."""
+    import subprocess
+    import sys as _sys
+
+    from vllm_production_stack_amd.engine.config import EngineConfig, KVOffloadConfig
+    from vllm_production_stack_amd.engine.llm_engine import LLMEngine
+    from vllm_production_stack_amd.engine.request import SamplingParams
+    from vllm_production_stack_amd.kv.remote import RemoteKVClient
+
+    port = 18455
+    srv = subprocess.Popen([_sys.executable, "-m", "vllm_production_stack_amd.cache_server", "127.0.0.1",
+                            str(port), "--max-size-gb", "24"])
+    url = f"lm://127.0.0.1:{port}"
+    try:
+        cli = RemoteKVClient(url)
+        for _ in range(100):
+            try:
+                cli.stats()
+                break
+            except OSError:
+                time.sleep(0.1)
+        blob = bytes(bytearray(os.urandom(1 << 20)) * 8)
+        n = 64
+        t0 = time.perf_counter()
+        for i in range(n):
+            cli.put(b"raw-%d" % i, blob)
+        t_put = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for i in range(n):
+            assert len(cli.get(b"raw-%d" % i)) == len(blob)
+        t_get = time.perf_counter() - t0
+        out = {"case": "remote", "serde": serde, "raw_put_gb_per_s": round(n * len(blob) / t_put / 1e9, 2),
+               "raw_get_gb_per_s": round(n * len(blob) / t_get / 1e9, 2)}
+
+        pages_per_seq = ctx // 64 + 2
+        cfg = EngineConfig(model="llama-3-8b", max_model_len=32000, max_num_seqs=8, max_num_batched_tokens=8192,
+                           num_gpu_blocks_override=2 * pages_per_seq + 8,
+                           kv_offload=KVOffloadConfig(remote_url=url, remote_serde=serde))
+        eng = LLMEngine(cfg)
+        g = torch.Generator().manual_seed(0)
+        sp = SamplingParams(max_tokens=1, temperature=0, ignore_eos=True)
+        eng.generate([torch.randint(16, 100000, (300,), generator=g).tolist()], copy.deepcopy(sp))
+        a = torch.randint(16, 100000, (ctx,), generator=g).tolist()
+
+        def first_token(p):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = eng.add_request(p, copy.deepcopy(sp))
+            while eng.has_work():
+                eng.step()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, r
+
+        t_cold, _ = first_token(a)
+        t0 = time.perf_counter()
+        want = ctx // 64
+        while cli.stats().get("keys", 0) < n + want - 1 and time.perf_counter() - t0 < 120:
+            time.sleep(0.05)  # background uploads of the fresh pages
+        out["upload_drain_s"] = round(time.perf_counter() - t0, 2)
+        eng.bm.reset_prefix_cache()
+        t_remote, r = first_token(a)
+        out.update({"ctx": ctx, "cold_recompute_s": round(t_cold, 4), "remote_reload_s": round(t_remote, 4),
+                    "remote_tokens": r.num_external_tokens, "server": cli.stats()})
+        eng.shutdown()
+        return out
+    finally:
+        srv.terminate()
+        srv.wait(timeout=10)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", default="copy,cachegen,ttft")
     a = ap.parse_args()
     for c in a.cases.split(","):
-        out = {"copy": copy_engine, "cachegen": cachegen, "ttft": ttft}[c]()
+        out = {"copy": copy_engine, "cachegen": cachegen, "ttft": ttft, "remote": remote,
+               "remote_cachegen": lambda: remote(serde="cachegen")}[c]()
         print(json.dumps(out), flush=True)
 
 

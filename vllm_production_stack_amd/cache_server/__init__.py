@@ -19,6 +19,7 @@ import argparse
 import asyncio
 import json
 import struct
+import sys
 from collections import OrderedDict
 
 OP_PUT, OP_GET, OP_EXISTS, OP_EXISTS_MANY, OP_DELETE, OP_STATS = 1, 2, 3, 4, 5, 6
@@ -31,6 +32,7 @@ class LRUStore:
         self.data: OrderedDict[bytes, bytes] = OrderedDict()
         self.bytes = 0
         self.hits = self.misses = self.puts = self.evictions = 0
+        self._spare: dict[int, list] = {}
 
     def put(self, k: bytes, v: bytes) -> None:
         old = self.data.pop(k, None)
@@ -43,6 +45,20 @@ class LRUStore:
             _, ev = self.data.popitem(last=False)
             self.bytes -= len(ev)
             self.evictions += 1
+            # reuse only a buffer nobody else holds (a queued response would keep a reference)
+            if isinstance(ev, bytearray) and len(ev) >= (1 << 20) and sys.getrefcount(ev) == 2:
+                spare = self._spare.setdefault(len(ev), [])
+                if len(spare) < 16:
+                    spare.append(ev)
+
+    def buffer(self, n: int):
+        """A writable buffer of ``n`` bytes for an incoming value.  Buffers of evicted values of
+        the same size are handed out again: pages all have one size, and a recycled buffer is
+        already mapped (a fresh 8 MiB allocation costs a page fault per 4 KiB)."""
+        pool = self._spare.get(n)
+        if pool:
+            return pool.pop()
+        return bytearray(n)
 
     def get(self, k: bytes) -> bytes | None:
         v = self.data.get(k)
@@ -59,56 +75,98 @@ class LRUStore:
                 "evictions": self.evictions}
 
 
+class _Conn(asyncio.BufferedProtocol):
+    """One client connection.  Requests are parsed with a four-state machine (op+key length,
+    key, value length, value) and the value bytes are received straight into the buffer that
+    the store will keep: no intermediate stream buffer, no joins.  Responses are written as
+    header and value separately for the same reason."""
+
+    def __init__(self, server: "CacheServer"):
+        self.server = server
+        self.transport: asyncio.Transport | None = None
+        self._small = bytearray(65536 + 16)
+        self._expect(0, 3)
+
+    def _expect(self, state: int, n: int, buf: bytearray | None = None) -> None:
+        self.state, self.need, self.got = state, n, 0
+        self.buf = buf if buf is not None else self._small
+
+    def connection_made(self, transport) -> None:
+        self.transport = transport
+        self.server._conns.add(self)
+
+    def connection_lost(self, exc) -> None:
+        self.server._conns.discard(self)
+
+    def get_buffer(self, sizehint: int) -> memoryview:
+        return memoryview(self.buf)[self.got:self.need]
+
+    def buffer_updated(self, nbytes: int) -> None:
+        self.got += nbytes
+        while self.got == self.need:
+            if self.state == 0:
+                self.op, klen = struct.unpack_from("<BH", self.buf, 0)
+                if klen:
+                    self._expect(1, klen)
+                    return
+                self.key = b""
+                self._expect(2, 8)
+                return
+            if self.state == 1:
+                self.key = bytes(self.buf[: self.need])
+                self._expect(2, 8)
+                return
+            if self.state == 2:
+                (vlen,) = struct.unpack_from("<Q", self.buf, 0)
+                if vlen > self.server.store.max_bytes + (1 << 20):
+                    self.transport.close()
+                    return
+                if vlen:
+                    self._expect(3, vlen, self.server.store.buffer(vlen))
+                    return
+                self._dispatch(b"")
+            else:
+                self._dispatch(self.buf)
+            self._expect(0, 3)
+            return
+
+    def _dispatch(self, val) -> None:
+        store, op, key = self.server.store, self.op, self.key
+        status, out = ST_OK, b""
+        if op == OP_PUT:
+            store.put(key, val)
+        elif op == OP_GET:
+            v = store.get(key)
+            status, out = (ST_OK, v) if v is not None else (ST_MISS, b"")
+        elif op == OP_EXISTS:
+            status = ST_OK if key in store.data else ST_MISS
+        elif op == OP_EXISTS_MANY:
+            keys = bytes(val).split(b"\n") if val else []
+            out = bytes(1 if k in store.data else 0 for k in keys)
+        elif op == OP_DELETE:
+            v = store.data.pop(key, None)
+            if v is not None:
+                store.bytes -= len(v)
+        elif op == OP_STATS:
+            out = json.dumps(store.stats()).encode()
+        else:
+            status = ST_ERR
+        self.transport.write(struct.pack("<BQ", status, len(out)))
+        if out:
+            self.transport.write(out)
+
+
 class CacheServer:
     def __init__(self, host: str = "0.0.0.0", port: int = 8000, max_bytes: int = 64 << 30):
         self.host, self.port = host, port
         self.store = LRUStore(max_bytes)
         self._server: asyncio.AbstractServer | None = None
-        self._conns: set[asyncio.Task] = set()
-
-    async def _handle(self, reader: asyncio.StreamReader, writer: asyncio.StreamWriter) -> None:
-        task = asyncio.current_task()
-        self._conns.add(task)
-        try:
-            while True:
-                try:
-                    hdr = await reader.readexactly(3)
-                except asyncio.IncompleteReadError:
-                    break
-                op, klen = struct.unpack("<BH", hdr)
-                key = await reader.readexactly(klen)
-                (vlen,) = struct.unpack("<Q", await reader.readexactly(8))
-                val = await reader.readexactly(vlen) if vlen else b""
-                status, out = ST_OK, b""
-                if op == OP_PUT:
-                    self.store.put(key, val)
-                elif op == OP_GET:
-                    v = self.store.get(key)
-                    status, out = (ST_OK, v) if v is not None else (ST_MISS, b"")
-                elif op == OP_EXISTS:
-                    status = ST_OK if key in self.store.data else ST_MISS
-                elif op == OP_EXISTS_MANY:
-                    keys = val.split(b"\n") if val else []
-                    out = bytes(1 if k in self.store.data else 0 for k in keys)
-                elif op == OP_DELETE:
-                    v = self.store.data.pop(key, None)
-                    if v is not None:
-                        self.store.bytes -= len(v)
-                elif op == OP_STATS:
-                    out = json.dumps(self.store.stats()).encode()
-                else:
-                    status = ST_ERR
-                writer.write(struct.pack("<BQ", status, len(out)) + out)
-                await writer.drain()
-        except (ConnectionResetError, BrokenPipeError, asyncio.CancelledError):
-            pass
-        finally:
-            self._conns.discard(task)
-            writer.close()
+        self._conns: set[_Conn] = set()
 
     async def start(self) -> "CacheServer":
-        self._server = await asyncio.start_server(self._handle, self.host, self.port,
-                                                  limit=1 << 26, reuse_address=True)
+        loop = asyncio.get_running_loop()
+        self._server = await loop.create_server(lambda: _Conn(self), self.host, self.port,
+                                                reuse_address=True, backlog=256)
         self.port = self._server.sockets[0].getsockname()[1]
         return self
 
@@ -116,12 +174,10 @@ class CacheServer:
         if self._server:
             self._server.close()
             await self._server.wait_closed()
-        # wait_closed() does not cover connections that are already open: end their handlers
-        conns = list(self._conns)
-        for t in conns:
-            t.cancel()
-        if conns:
-            await asyncio.gather(*conns, return_exceptions=True)
+        for c in list(self._conns):  # wait_closed() does not cover connections already open
+            if c.transport is not None:
+                c.transport.close()
+        self._conns.clear()
 
 
 def main(argv: list[str] | None = None) -> None:

@@ -58,6 +58,21 @@ class KVConnector:
             self.host = HostKVPool(self.pool, cap, on_spill=self._spill)
         self.remote = RemoteKVClient(off.remote_url) if off.remote_url else None
         self.remote_known: set[int] = set()
+        self.remote_dropped = 0  # fresh pages given up on because the server stopped draining the ring
+        # Raw (naive) pages of a GPU replica travel through a ring of pinned staging slots:
+        # device -> slot on a side stream, slot -> socket on the background thread (and the
+        # other way round on load), so the step loop never waits for a host copy or a send.
+        self._stage = None
+        self._pool_exec = None  # worker threads of the codec path, created on first use
+        self._inflight: set[int] = set()  # hashes whose upload has been queued but not finished
+        if (self.remote is not None and self.pool.is_cuda and self.serde.kind == 0
+                and self.pool[0].numel() == self.serde.page_elems):
+            n_stage = 128  # 1 GiB of pinned memory at 8 MiB per page
+            self._stage = torch.empty((n_stage, self.serde.page_elems), dtype=self.pool.dtype, pin_memory=True)
+            self._stage_free: queue.Queue = queue.Queue()
+            for i in range(n_stage):
+                self._stage_free.put(i)
+            self._remote_stream = torch.cuda.Stream(device=self.device)
         self._pending: list[tuple[object, list[int]]] = []  # (event, page ids holding a ref)
         self._bg: queue.Queue = queue.Queue()
         self._bg_thread = threading.Thread(target=self._bg_loop, name="kv-bg", daemon=True)
@@ -150,10 +165,33 @@ class KVConnector:
                 from_host.append((h, p))
             else:
                 slow.append((h, p))
+        if self._stage is not None and slow:
+            on_disk = [(h, p) for h, p in slow if self.disk is not None and self.disk.contains(h)]
+            fetched = [(h, p) for h, p in slow if (h, p) not in set(on_disk)]
+            missing = self._download_staged(fetched)
+            if self.host is not None:
+                done = [x for x in fetched if x not in set(missing)]
+                if done:
+                    self.host.store(done)
+            slow = on_disk + missing
+        elif self.remote is not None and self.serde.kind != 0 and slow:
+            on_disk = [(h, p) for h, p in slow if self.disk is not None and self.disk.contains(h)]
+            fetched = [x for x in slow if x not in set(on_disk)]
+            missing = self._download_codec(fetched)
+            if self.host is not None:
+                done = [x for x in fetched if x not in set(missing)]
+                if done:
+                    self.host.store(done)
+            slow = on_disk + missing
         for h, p in slow:  # disk / remote: decode on this thread, then a plain H2D copy
             t = self.disk.get(h, self.device) if self.disk is not None and self.disk.contains(h) else None
             if t is None and self.remote is not None:
                 blob = self.remote.get(RemoteKVClient.key(h))
+                for _ in range(100):  # our own upload of this page may still be on its way
+                    if blob is not None or h not in self._inflight:
+                        break
+                    time.sleep(0.05)
+                    blob = self.remote.get(RemoteKVClient.key(h))
                 if blob is not None:
                     t = self.serde.decode(blob, self.device)
             if t is None:
@@ -180,13 +218,23 @@ class KVConnector:
                 self._pending.append((ev, pages))
             self.metrics.kv_local_usage.set(self.host.used_bytes())
             self.metrics.cpu_cache_usage.set(len(self.host.index) / self.host.n_slots)
-        if self.remote is not None:
+        if self.remote is not None and self._stage is not None:
+            self._upload_staged([(h, p) for h, p in fresh if h not in self.remote_known])
+        elif self.remote is not None:
             for h, p in fresh:
                 if h in self.remote_known:
                     continue
-                blob = self.serde.encode(self.pool[p])
                 self.remote_known.add(h)
-                self._bg.put(lambda k=RemoteKVClient.key(h), b=blob: self.remote.put(k, b))
+                page = self.pool[p]
+                if self.serde.uses_codec(page):
+                    # quantise on the GPU here; the range coder (tens of ms per page) and the
+                    # upload run on the worker pool
+                    sym, sc = self.serde.quantize(page.reshape(-1))
+                    self._inflight.add(h)
+                    self._workers().submit(self._pack_and_put, h, sym, sc)
+                else:
+                    blob = self.serde.encode(page)
+                    self._bg.put(lambda k=RemoteKVClient.key(h), b=blob: self.remote.put(k, b))
         elif self.disk is not None and self.host is None:
             for h, p in fresh:
                 self.disk.put(h, self.pool[p].cpu())
@@ -197,6 +245,121 @@ class KVConnector:
         dt = max(time.time() - t0, 1e-6)
         self.metrics.kv_store_speed.observe(len(fresh) * PAGE / dt)
         self.poll()
+
+    def _workers(self):
+        if self._pool_exec is None:
+            import os
+            from concurrent.futures import ThreadPoolExecutor
+
+            n = max(2, min(16, (os.cpu_count() or 4) // 2))
+            self._pool_exec = ThreadPoolExecutor(max_workers=n, thread_name_prefix="kv-codec")
+        return self._pool_exec
+
+    def _pack_and_put(self, h: int, sym, sc) -> None:
+        try:
+            if not self.remote.put(RemoteKVClient.key(h), self.serde.pack(sym, sc)):
+                self.remote_known.discard(h)
+        except Exception as e:
+            self.remote_known.discard(h)
+            log.warning("remote KV upload of %016x failed: %s", h, e)
+        finally:
+            self._inflight.discard(h)
+
+    def _fetch_unpacked(self, h: int):
+        blob = self.remote.get(RemoteKVClient.key(h))
+        return None if blob is None else self.serde.unpack(blob)
+
+    def _download_codec(self, items: list[tuple[int, int]]) -> list[tuple[int, int]]:
+        """Remote pages in codec form: fetch + entropy-decode on the worker pool (in page
+        order, so the GPU half of page i overlaps the host half of the following pages)."""
+        left: list[tuple[int, int]] = []
+        futs = [self._workers().submit(self._fetch_unpacked, h) for h, _ in items]
+        for (h, p), f in zip(items, futs):
+            got = f.result()
+            if got is None:
+                left.append((h, p))
+            elif got[0] == "raw":
+                t = torch.from_numpy(got[1]).view(self.pool.dtype)
+                self.pool[p].view(-1).copy_(t.to(self.device))
+            else:
+                self.pool[p].view(-1).copy_(self.serde.dequantize(got[1], got[2], self.device).view(-1))
+        return left
+
+    def _upload_staged(self, todo: list[tuple[int, int]]) -> None:
+        """Raw pages to the remote server without blocking the step loop."""
+        taken: list[tuple[int, int, int]] = []
+        for i, (h, p) in enumerate(todo):
+            try:
+                # a full ring means the uploads are behind the prefill: wait for a slot (a
+                # dropped page would cut the hash chain and orphan every later page)
+                taken.append((h, p, self._stage_free.get(timeout=10.0)))
+            except queue.Empty:
+                self.remote_dropped += len(todo) - i
+                break
+        if not taken:
+            return
+        st = self._remote_stream
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(st):
+            for _h, p, slot in taken:
+                self._stage[slot].copy_(self.pool[p].reshape(-1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        pages = [p for _, p, _ in taken]
+        for p in pages:  # the HBM pages must stay put until the side-stream copy has read them
+            self.engine.bm.ref[p] += 1
+        self._pending.append((_TorchEvent(ev), pages))
+        for h, _, _ in taken:
+            self.remote_known.add(h)
+            self._inflight.add(h)
+        header = self.serde._header(self.serde.page_elems * self._stage.element_size())
+
+        def send(taken=taken, ev=ev):
+            ev.synchronize()
+            for h, _p, slot in taken:
+                try:
+                    view = memoryview(self._stage[slot].view(torch.uint8).numpy())
+                    if not self.remote.put_parts(RemoteKVClient.key(h), header, view):
+                        self.remote_known.discard(h)
+                except Exception:
+                    self.remote_known.discard(h)
+                    raise
+                finally:
+                    self._inflight.discard(h)
+                    self._stage_free.put(slot)
+
+        self._bg.put(send)
+
+    def _download_staged(self, items: list[tuple[int, int]]) -> list[tuple[int, int]]:
+        """Raw remote pages -> pinned slot -> HBM page (async H2D); returns the items that were
+        not served this way (miss or a blob of another format)."""
+        left: list[tuple[int, int]] = []
+        hdr_len = len(self.serde._header(0))
+        want = self.serde._header(self.serde.page_elems * self._stage.element_size())
+        stream = torch.cuda.current_stream(self.device)
+        used: list[int] = []
+        for h, p in items:
+            try:
+                slot = self._stage_free.get_nowait()
+            except queue.Empty:
+                stream.synchronize()  # the copies out of the slots taken so far have landed
+                for sl in used:
+                    self._stage_free.put(sl)
+                used = []
+                slot = self._stage_free.get()
+            view = memoryview(self._stage[slot].view(torch.uint8).numpy())
+            hdr = self.remote.get_page_into(RemoteKVClient.key(h), hdr_len, view)
+            if hdr != want:
+                self._stage_free.put(slot)
+                left.append((h, p))
+                continue
+            self.pool[p].view(-1).copy_(self._stage[slot], non_blocking=True)
+            used.append(slot)
+        if used:
+            stream.synchronize()
+            for sl in used:
+                self._stage_free.put(sl)
+        return left
 
     def poll(self) -> None:
         """Release page references whose offload copies have completed."""
@@ -252,6 +415,8 @@ class KVConnector:
             return
         self._closed = True
         self._bg.put(None)
+        if self._pool_exec is not None:
+            self._pool_exec.shutdown(wait=True)
         for ev, pages in self._pending:
             ev.wait()
             self.engine.bm.free(pages)
@@ -260,6 +425,19 @@ class KVConnector:
             self.host.close()
         if self.remote is not None:
             self.remote.close()
+
+
+class _TorchEvent:
+    """Gives a torch event the query/wait pair the pending-copy list expects."""
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def query(self) -> bool:
+        return self.ev.query()
+
+    def wait(self) -> None:
+        self.ev.synchronize()
 
 
 class _ComputeFence:

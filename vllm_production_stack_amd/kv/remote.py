@@ -66,6 +66,60 @@ class RemoteKVClient:
         raise ConnectionError("unreachable")
 
     @staticmethod
+    def _recv_into(s: socket.socket, view: memoryview) -> None:
+        got, n = 0, len(view)
+        while got < n:
+            k = s.recv_into(view[got:], n - got)
+            if k == 0:
+                raise ConnectionError("cache server closed the connection")
+            got += k
+
+    def put_parts(self, key: bytes, *parts) -> bool:
+        """PUT whose value is the concatenation of ``parts`` (bytes or memoryviews), sent
+        without joining them: a page goes from its pinned staging slot straight to the socket."""
+        total = sum(len(p) for p in parts)
+        for attempt in (0, 1):
+            try:
+                s = self._sock()
+                s.sendall(struct.pack("<BH", OP_PUT, len(key)) + key + struct.pack("<Q", total))
+                for part in parts:
+                    s.sendall(part)
+                status, vlen = struct.unpack("<BQ", self._recv(s, 9))
+                if vlen:
+                    self._recv(s, vlen)
+                return status == ST_OK
+            except (OSError, ConnectionError):
+                self._drop()
+                if attempt:
+                    raise
+        return False
+
+    def get_page_into(self, key: bytes, header_len: int, payload: memoryview) -> bytes | None:
+        """GET of a value laid out as ``header | payload``: the payload is received directly
+        into ``payload`` (e.g. pinned memory).  Returns the header, or None on a miss or when
+        the stored value does not have that size (the caller then takes the generic path)."""
+        for attempt in (0, 1):
+            try:
+                s = self._sock()
+                s.sendall(struct.pack("<BH", OP_GET, len(key)) + key + struct.pack("<Q", 0))
+                status, vlen = struct.unpack("<BQ", self._recv(s, 9))
+                if status != ST_OK:
+                    if vlen:
+                        self._recv(s, vlen)
+                    return None
+                if vlen != header_len + len(payload):
+                    self._recv(s, vlen)
+                    return None
+                hdr = self._recv(s, header_len)
+                self._recv_into(s, payload)
+                return hdr
+            except (OSError, ConnectionError):
+                self._drop()
+                if attempt:
+                    raise
+        return None
+
+    @staticmethod
     def key(h: int, prefix: str = "") -> bytes:
         return f"{prefix}{h:016x}".encode()
 

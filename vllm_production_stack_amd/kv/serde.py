@@ -88,16 +88,28 @@ class PageSerde:
             raw = flat.contiguous().cpu().view(torch.uint8).numpy().tobytes()
             return _HDR.pack(MAGIC, 1, SERDE_NAIVE, self.n_layers, self.n_kv, self.head_dim, ops.PAGE,
                              len(raw)) + raw
+        sym_np, sc_np = self.quantize(flat)
+        return self.pack(sym_np, sc_np)
+
+    def quantize(self, flat: torch.Tensor) -> tuple[np.ndarray, np.ndarray]:
+        """GPU half of the cachegen encoder: anchor/delta quantisation kernel, then the int8
+        symbols and fp32 scales come to the host."""
         lv = self._levels_dev.get(flat.device)
         if lv is None:
             lv = torch.tensor(self.levels, dtype=torch.int32, device=flat.device)
             self._levels_dev[flat.device] = lv
         sym, scales = ops.cachegen_encode(flat.contiguous(), lv, self.unit_elems, self.n_layers)
-        sym_np = sym.cpu().numpy()
+        return sym.cpu().numpy(), scales.float().cpu().numpy()
+
+    def pack(self, sym_np: np.ndarray, sc_np: np.ndarray) -> bytes:
+        """Host half: range-code the symbols (releases the GIL: safe to run on worker threads)."""
         coded = rc_encode(sym_np, 2 * self.unit_elems, self.n_layers)
-        sc = scales.float().cpu().numpy().tobytes()
-        payload = sc + struct.pack("<Q", len(coded)) + coded
+        payload = sc_np.tobytes() + struct.pack("<Q", len(coded)) + coded
         return self._header(len(payload)) + payload
+
+    def uses_codec(self, page: torch.Tensor) -> bool:
+        return (self.kind == SERDE_CACHEGEN and self.unit_elems % 8192 == 0
+                and page.dtype == torch.bfloat16)
 
     # ------------------------------------------------------------------ decode
     def decode(self, blob: bytes, device: torch.device) -> torch.Tensor:
@@ -110,9 +122,30 @@ class PageSerde:
         if kind == SERDE_NAIVE:
             t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).view(self.dtype)
             return t.to(device)
+        sym_np, sc_np = self._unpack_payload(payload)
+        return self.dequantize(sym_np, sc_np, device)
+
+    def _unpack_payload(self, payload) -> tuple[np.ndarray, np.ndarray]:
         n_groups = self.page_elems // 64
-        scales = torch.frombuffer(bytearray(payload[: 4 * n_groups]), dtype=torch.float32)
+        scales = np.frombuffer(payload[: 4 * n_groups], dtype=np.float32).copy()
         (clen,) = struct.unpack_from("<Q", payload, 4 * n_groups)
         coded = bytes(payload[4 * n_groups + 8: 4 * n_groups + 8 + clen])
-        sym = torch.from_numpy(rc_decode(coded, self.page_elems, 2 * self.unit_elems, self.n_layers))
+        return rc_decode(coded, self.page_elems, 2 * self.unit_elems, self.n_layers), scales
+
+    def unpack(self, blob: bytes):
+        """Host half of decode for worker threads: ("raw", uint8 array) for a naive blob,
+        ("codec", symbols, scales) for a cachegen one."""
+        magic, ver, kind, nl, nkv, hd, pt, plen = _HDR.unpack_from(blob, 0)
+        if magic != MAGIC or ver != 1:
+            raise ValueError("not a KV page blob")
+        if (nl, nkv, hd, pt) != (self.n_layers, self.n_kv, self.head_dim, ops.PAGE):
+            raise ValueError("KV page geometry mismatch")
+        payload = memoryview(blob)[_HDR.size:_HDR.size + plen]
+        if kind == SERDE_NAIVE:
+            return ("raw", np.frombuffer(payload, dtype=np.uint8).copy())
+        return ("codec",) + self._unpack_payload(payload)
+
+    def dequantize(self, sym_np: np.ndarray, sc_np: np.ndarray, device: torch.device) -> torch.Tensor:
+        sym = torch.from_numpy(sym_np)
+        scales = torch.from_numpy(sc_np)
         return ops.cachegen_decode(sym.to(device), scales.to(device), self.unit_elems)
