@@ -54,6 +54,8 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--cpu-offload-gb", type=float, default=0.0)
     ap.add_argument("--num-gpu-blocks", type=int, default=0,
                     help="cap the HBM KV pool (pages of 64 tokens) to exercise the host tier; 0 = size from HBM")
+    ap.add_argument("--prefill-step-ms", type=float, default=30.0,
+                    help="engine's latency-aware prefill admission target (0 = token budget only)")
     ap.add_argument("--base-port", type=int, default=int(os.environ.get("VPSA_BENCH_PORT", "18100")))
     ap.add_argument("--clients", type=int, default=0, help="load-generator processes (0 = auto)")
     ap.add_argument("--device", default="cuda", help="cpu runs a plumbing rehearsal (tiny models)")
@@ -178,7 +180,8 @@ async def rank_main(a: argparse.Namespace) -> None:
                            port=a.base_port + 1 + rank, max_model_len=a.max_model_len,
                            max_num_seqs=256, max_num_batched_tokens=a.max_num_batched_tokens,
                            enable_prefix_caching=True, enable_chunked_prefill=True, kv_offload=off,
-                           num_gpu_blocks_override=a.num_gpu_blocks or None)
+                           num_gpu_blocks_override=a.num_gpu_blocks or None,
+                           prefill_step_ms=a.prefill_step_ms)
         engine = LLMEngine(cfg)
         ae = AsyncLLMEngine(engine)
         ae.start(loop)
@@ -254,7 +257,8 @@ async def rank_main(a: argparse.Namespace) -> None:
                            "rounds": a.steps, "parallelism": f"dp{n} (replicas behind router)",
                            "routing": a.routing_logic,
                            "kv_pages_per_replica": engine.runner.num_pages,
-                           "cpu_offload_gb": a.cpu_offload_gb},
+                           "cpu_offload_gb": a.cpu_offload_gb,
+                           "prefill_step_ms": a.prefill_step_ms},
                 "kv_tiers": ({"host_loads_pages": engine.connector.host.loads,
                               "host_stores_pages": engine.connector.host.stores,
                               "host_evictions_pages": engine.connector.host.evictions}

@@ -179,3 +179,40 @@ def test_kernel_launches_move_the_calling_thread_to_the_bound_gpu(monkeypatch):
     finally:
         ops.bind_device(None)
     assert calls == [(threading.current_thread().name, 3), ("fresh", 3)]
+
+
+def test_latency_aware_prefill_admission_splits_a_burst_of_follow_up_turns():
+    """With a prefill cost model, a burst of short prompts is spread over several steps (each
+    under the step target) and a single long prompt is still taken whole; without it the token
+    budget alone decides."""
+    from vllm_production_stack_amd.engine.block_manager import BlockManager
+    from vllm_production_stack_amd.engine.request import Request, SamplingParams
+    from vllm_production_stack_amd.engine.scheduler import Scheduler
+
+    def burst(sched, n, length):
+        for i in range(n):
+            sched.add(Request(f"r{i}", [1000 * (i + 1) + j for j in range(length)], SamplingParams(max_tokens=4)))
+
+    plain = Scheduler(BlockManager(512, True), 64, 8192, 4096)
+    burst(plain, 12, 100)
+    assert len(plain.schedule().prefills) == 12
+
+    timed = Scheduler(BlockManager(512, True), 64, 8192, 4096)
+    timed.prefill_cost_ms = lambda n, start: n * 0.1  # 10 ms per 100-token prompt
+    timed.prefill_step_ms = 35.0
+    burst(timed, 12, 100)
+    sizes = []
+    for _ in range(6):
+        out = timed.schedule()
+        sizes.append(len(out.prefills))
+        for s in out.prefills + out.decodes:
+            timed.commit(s)
+            s.req.output_ids.append(1)
+    assert sizes[:4] == [3, 3, 3, 3] and sum(sizes) == 12
+
+    alone = Scheduler(BlockManager(512, True), 64, 8192, 4096)
+    alone.prefill_cost_ms = lambda n, start: n * 0.1
+    alone.prefill_step_ms = 35.0
+    burst(alone, 1, 3000)  # 300 ms estimated: still scheduled (the first prefill always is)
+    out = alone.schedule()
+    assert [s.n for s in out.prefills] == [3000]

@@ -48,6 +48,13 @@ class ModelConfig:
     def kv_size(self) -> int:
         return self.num_kv_heads * self.head_dim
 
+    def prefill_flops(self) -> tuple[float, float]:
+        """(GEMM FLOPs per new token, attention FLOPs per (new token x context token) pair)."""
+        h, i = self.hidden_size, self.intermediate_size
+        attn_w = h * (self.q_size + 2 * self.kv_size) + self.q_size * h
+        mlp_w = 3 * h * i * max(1, self.num_experts_per_tok if self.num_experts else 1)
+        return 2.0 * self.num_layers * (attn_w + mlp_w), 4.0 * self.num_layers * self.q_size
+
     def num_params(self) -> int:
         h, i, l_ = self.hidden_size, self.intermediate_size, self.num_layers
         attn = h * (self.q_size + 2 * self.kv_size) + self.q_size * h
@@ -269,6 +276,13 @@ class EngineConfig:
     swap_space: float = 0.0
     enforce_eager: bool = False
     capture_graphs_at_start: bool = True  # HIP graphs for all decode batch buckets at start-up
+    # Latency-aware prefill admission: after the first prefill of a step, more waiting requests
+    # join only while the estimated prefill time of the step stays under this many ms
+    # (0 = fill the token budget).  The estimate prices GEMM and attention FLOPs at the rates
+    # below (what the library GEMM and the prefill attention kernel sustain on one MI355X).
+    prefill_step_ms: float = 30.0
+    gemm_tflops_estimate: float = 1500.0
+    attn_tflops_estimate: float = 900.0
     seed: int = 0
     api_key: str | None = None
     disable_log_requests: bool = False

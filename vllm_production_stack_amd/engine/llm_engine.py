@@ -40,6 +40,13 @@ class LLMEngine:
         self.bm = BlockManager(self.runner.num_pages, cfg.enable_prefix_caching or cfg.kv_offload.enabled)
         self.scheduler = Scheduler(self.bm, cfg.max_num_seqs, cfg.max_num_batched_tokens,
                                    self.max_model_len, cfg.enable_chunked_prefill)
+        if self.device.type == "cuda" and cfg.prefill_step_ms > 0:
+            gemm_f, attn_f = self.model_cfg.prefill_flops()
+            tp = max(1, cfg.tensor_parallel_size)
+            g_ms = gemm_f / tp / (cfg.gemm_tflops_estimate * 1e9)
+            a_ms = attn_f / tp / (cfg.attn_tflops_estimate * 1e9)
+            self.scheduler.prefill_cost_ms = lambda n, start: n * g_ms + n * (start + 0.5 * n) * a_ms
+            self.scheduler.prefill_step_ms = cfg.prefill_step_ms
         self.metrics = EngineMetrics(cfg.model_name)
         self.requests: dict[str, Request] = {}
         self.eos_ids = {self.tokenizer.eos_token_id, self.model_cfg.eos_token_id} if self.ckpt_dir else {

@@ -54,6 +54,15 @@ class Scheduler:
         self.max_num_batched_tokens = max_num_batched_tokens if enable_chunked_prefill else max(
             max_num_batched_tokens, max_model_len)
         self.connector = connector
+        # Latency-aware admission: ``prefill_cost_ms(n_new_tokens, n_cached_tokens)`` estimates
+        # the GPU time of one sequence's prefill rows.  The first prefill of a step is always
+        # taken (up to the token budget); further waiting requests join only while the summed
+        # estimate stays under ``prefill_step_ms``.  A burst of short follow-up turns is then
+        # served in several short steps (most users see their first token after one of them)
+        # instead of one long step that everybody waits for.  A step whose first prefill alone
+        # exceeds the target is filled to the token budget as usual.  None / 0 = token budget only.
+        self.prefill_cost_ms = None
+        self.prefill_step_ms = 0.0
         self.waiting: deque[Request] = deque()
         self.running: list[Request] = []
         self.num_preemptions = 0
@@ -176,6 +185,9 @@ class Scheduler:
             (out.decodes if n == 1 and req.num_computed > 0 else out.prefills).append(seq)
             budget -= n
 
+        timed = self.prefill_cost_ms is not None and self.prefill_step_ms > 0
+        spent_ms = sum(self.prefill_cost_ms(s.n, s.start) for s in out.prefills) if timed else 0.0
+
         # 2. admit waiting requests FCFS
         while self.waiting and budget > 0 and len(self.running) < self.max_num_seqs:
             req = self.waiting[0]
@@ -185,6 +197,13 @@ class Scheduler:
                 self._admit(req)
             rem = req.remaining
             n = min(rem, budget)
+            if timed:
+                cost = self.prefill_cost_ms(n, req.num_computed)
+                # A step that is already long (a chunk of a long prompt) is filled up to the
+                # token budget as before: the rule only keeps short steps short.
+                if out.prefills and spent_ms <= self.prefill_step_ms < spent_ms + cost:
+                    break  # next step; its cached pages stay attached (the request is next in line)
+                spent_ms += cost
             if not self.enable_chunked_prefill and n < rem:
                 if not out.prefills and not out.decodes and rem > self.max_num_batched_tokens:
                     n = rem  # oversize prompt running alone
