@@ -82,7 +82,7 @@ def prefill_case(name: str, n_seqs: int, q_len: int, prefix: int, iters: int,
     for v in variants:
         ms = sorted(samples[v])[1]
         res[f"variant{v}"] = {"ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 1)}
-    ops.set_prefill_variant(2)
+    ops.set_prefill_variant(-1)
     return res
 
 
@@ -120,7 +120,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--cases", default="prefill_cold,prefill_warm,decode")
-    ap.add_argument("--variants", default="0,1,2", help="prefill kernel generations to time")
+    ap.add_argument("--variants", default="0,1,2,3,-1", help="prefill kernels to time (-1 = automatic choice)")
     a = ap.parse_args()
     cases = a.cases.split(",")
     variants = tuple(int(v) for v in a.variants.split(","))

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
 // ---------------------------------------------------------------------------------
 #define LAZY_THR 6.0f
 
-template <bool PRIO>
+template <bool PRIO, bool HEAD_MAJOR>
 __global__ __launch_bounds__(256, 2) void paged_prefill_kernel_v2(
     const uint16_t* __restrict__ q, long q_stride, uint16_t* __restrict__ out, long out_stride,
     const uint16_t* __restrict__ cache, long page_stride, long v_offset,
@@ -261,16 +261,27 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel_v2(
   const int r = lane & 31;
   const int h = lane >> 5;
 
+  // Workgroups are handed to the 8 XCDs round-robin in linear launch order.  HEAD_MAJOR makes
+  // the (kv head, head group) index the fastest-varying one, so that all q-tiles that read one
+  // KV head's keys run on one XCD and share its L2 (8 KV heads <-> 8 XCDs for Llama-3).  It pays
+  // when a sequence has many q-tiles (chunks of long prompts: +6 %); with one tile per sequence
+  // there is nothing to share and the plain order is 14 % faster, so the launcher picks.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (HEAD_MAJOR) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    by = lin % gridDim.y;
+    bx = lin / gridDim.y;
+  }
   const int G = n_q / n_kv;
   const int GP = G < 4 ? G : 4;
   const int groups_per_kv = G / GP;
-  const int kvh = blockIdx.y / groups_per_kv;
-  const int hg = blockIdx.y % groups_per_kv;
+  const int kvh = by / groups_per_kv;
+  const int hg = by % groups_per_kv;
   const int head = kvh * G + hg * GP + (wave % GP);
   const int qsub = wave / GP;
 
-  const int seq = tile_seq[blockIdx.x];
-  const int q0 = tile_q0[blockIdx.x];
+  const int seq = tile_seq[bx];
+  const int q0 = tile_q0[bx];
   const int row0 = cu_q[seq];
   const int q_len = cu_q[seq + 1] - row0;
   const int ctx = ctx_lens[seq];
@@ -463,7 +474,10 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel_v2(
 
 // Kernel selection for in-process A/B timing (0 = first generation, 1 = second generation,
 // 2 = second generation with raised wave priority around the MFMA clusters).
-static int g_prefill_variant = 2;
+// -1 = automatic (generation 2; head-major tile order when sequences have many q-tiles);
+// 0 = first generation, 1 = generation 2 without wave priorities, 2 = generation 2,
+// 3 = generation 2 with head-major tile order  (fixed choices are for A/B timing and tests)
+static int g_prefill_variant = -1;
 VPSA_EXPORT int vpsa_set_prefill_variant(int v) {
   const int old = g_prefill_variant;
   g_prefill_variant = v;
@@ -474,7 +488,7 @@ VPSA_EXPORT int vpsa_paged_prefill(const void* q, long q_stride, void* out, long
                                    const void* cache, long page_stride, long v_offset,
                                    const int* block_tables, int max_blocks, const int* cu_q,
                                    const int* ctx_lens, const int* tile_seq, const int* tile_q0,
-                                   int num_tiles, int n_q, int n_kv, float scale,
+                                   int num_tiles, int num_seqs, int n_q, int n_kv, float scale,
                                    hipStream_t stream) {
   if (num_tiles <= 0) return 0;
   if (n_q % n_kv != 0) return -1;
@@ -484,17 +498,22 @@ VPSA_EXPORT int vpsa_paged_prefill(const void* q, long q_stride, void* out, long
   const int GP = G < 4 ? G : 4;
   dim3 grid(num_tiles, n_kv * (G / GP)), block(256);
   const float sl2 = scale * 1.4426950408889634f;
+  int variant = g_prefill_variant;
+  if (variant < 0) variant = (num_seqs > 0 && num_tiles >= 8 * num_seqs) ? 3 : 2;
 #define VPSA_PREFILL_ARGS                                                                      \
   (const uint16_t*)q, q_stride, (uint16_t*)out, out_stride, (const uint16_t*)cache,             \
       page_stride, v_offset, block_tables, max_blocks, cu_q, ctx_lens, tile_seq, tile_q0, n_q,  \
       n_kv, sl2
-  if (g_prefill_variant == 0) {
+  if (variant == 0) {
     hipLaunchKernelGGL(paged_prefill_kernel, grid, block, 32768, stream, VPSA_PREFILL_ARGS);
-  } else if (g_prefill_variant == 2) {
-    hipLaunchKernelGGL(paged_prefill_kernel_v2<true>, grid, block, 65536, stream,
+  } else if (variant == 3) {
+    hipLaunchKernelGGL((paged_prefill_kernel_v2<true, true>), grid, block, 65536, stream,
+                       VPSA_PREFILL_ARGS);
+  } else if (variant == 2) {
+    hipLaunchKernelGGL((paged_prefill_kernel_v2<true, false>), grid, block, 65536, stream,
                        VPSA_PREFILL_ARGS);
   } else {
-    hipLaunchKernelGGL(paged_prefill_kernel_v2<false>, grid, block, 65536, stream,
+    hipLaunchKernelGGL((paged_prefill_kernel_v2<false, false>), grid, block, 65536, stream,
                        VPSA_PREFILL_ARGS);
   }
 #undef VPSA_PREFILL_ARGS

@@ -81,8 +81,9 @@ def _block_tables(n_seqs, max_pages, total_pages, seed):
     return perm.view(n_seqs, max_pages).to(torch.int32).to(DEV)
 
 
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3])
 @pytest.mark.parametrize("n_q,n_kv", [(32, 8), (8, 8), (8, 4), (16, 2)])
-def test_paged_prefill_matches_reference(n_q, n_kv):
+def test_paged_prefill_matches_reference(n_q, n_kv, variant):
     torch.manual_seed(4)
     hd, layers = 128, 2
     # (new rows, cached prefix) per sequence: ragged tails, prefix hits, a 1-row chunk
@@ -102,7 +103,11 @@ def test_paged_prefill_matches_reference(n_q, n_kv):
     out = torch.zeros_like(q)
     out_ref = torch.zeros_like(q)
     scale = 1.0 / math.sqrt(hd)
-    ops.paged_prefill(q, out, pool, 1, bt, cu, ctx_t, ts, tq, n_q, n_kv, hd, scale)
+    prev = ops.set_prefill_variant(variant)
+    try:
+        ops.paged_prefill(q, out, pool, 1, bt, cu, ctx_t, ts, tq, n_q, n_kv, hd, scale)
+    finally:
+        ops.set_prefill_variant(prev)
     ref.paged_prefill(q, out_ref, pool, 1, bt, cu, ctx_t, n_q, n_kv, hd, scale)
     torch.cuda.synchronize()
     err = (out.float() - out_ref.float()).abs().max().item()

@@ -34,6 +34,8 @@ def _kernels():
             "vpsa_moe_gemv", "vpsa_moe_mfma", "vpsa_lora_shrink", "vpsa_lora_expand",
         ):
             getattr(lib, name).restype = c_int
+        if os.environ.get("VPSA_PREFILL_VARIANT"):  # pin one prefill kernel for A/B runs
+            lib.vpsa_set_prefill_variant(c_int(int(os.environ["VPSA_PREFILL_VARIANT"])))
         _lib = lib
     return _lib
 
@@ -43,8 +45,9 @@ def native_loaded() -> bool:
 
 
 def set_prefill_variant(v: int) -> int:
-    """Select the prefill attention kernel generation (for in-process A/B timing and tests).
-    Returns the previous selection."""
+    """Select the prefill attention kernel (for in-process A/B timing and tests): -1 automatic,
+    0 first generation, 1 second generation without wave priorities, 2 second generation,
+    3 second generation with head-major tile order.  Returns the previous selection."""
     return int(_kernels().vpsa_set_prefill_variant(c_int(v)))
 
 
@@ -166,7 +169,8 @@ def paged_prefill(q, out, pool, layer, block_tables, cu_q, ctx_lens, tile_seq, t
         _p(q), c_long(q.stride(0)), _p(out), c_long(out.stride(0)), c_void_p(base),
         c_long(pool.stride(0)), c_long(pool.stride(2)), _p(block_tables),
         c_int(block_tables.stride(0)), _p(cu_q), _p(ctx_lens), _p(tile_seq), _p(tile_q0),
-        c_int(tile_seq.numel()), c_int(n_q), c_int(n_kv), c_float(scale), _stream())
+        c_int(tile_seq.numel()), c_int(ctx_lens.numel()), c_int(n_q), c_int(n_kv), c_float(scale),
+        _stream())
     _check(rc, "paged_prefill")
 
 
