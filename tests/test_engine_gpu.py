@@ -170,3 +170,21 @@ def test_speech_model_bf16_tracks_fp32_on_gpu():
     toks = m16.transcribe_windows(waves, [prompt, prompt], max_new_tokens=12)
     assert len(toks) == 2 and all(len(x) <= 12 for x in toks)
     assert all(tok < cfg.eos_token_id for x in toks for tok in x)
+
+
+def test_opt_head_dim_64_runs_on_the_generic_attention_path():
+    """OPT-125m class models (head_dim 64) are outside the HIP attention kernels' shape: on a GPU
+    they take the PyTorch attention definitions, eagerly (no graphs), and must still serve."""
+    from vllm_production_stack_amd.engine.config import EngineConfig
+    from vllm_production_stack_amd.engine.llm_engine import LLMEngine
+    from vllm_production_stack_amd.engine.request import SamplingParams
+
+    eng = LLMEngine(EngineConfig(model="opt-125m", max_model_len=1024, max_num_seqs=4,
+                                 num_gpu_blocks_override=32))
+    assert not eng.runner.use_graphs
+    g = torch.Generator().manual_seed(0)
+    prompts = [torch.randint(16, 5000, (n,), generator=g).tolist() for n in (130, 7)]
+    outs = eng.generate(prompts, SamplingParams(max_tokens=6, temperature=0, ignore_eos=True))
+    assert all(len(o) == 6 for o in outs)
+    again = eng.generate(prompts[:1], SamplingParams(max_tokens=6, temperature=0, ignore_eos=True))
+    assert again[0] == outs[0]  # second pass goes through the prefix cache

@@ -68,7 +68,9 @@ class ModelRunner:
             dtype=self.dtype, device=device)
         self.sampler = Sampler(device, cfg.seed)
         # collectives and stage hand-offs run eagerly: graphs only for single-process replicas
-        self.use_graphs = device.type == "cuda" and not cfg.enforce_eager and not self.distributed
+        # graphs need the HIP attention kernels (the generic path reads lengths on the host)
+        self.use_graphs = (device.type == "cuda" and not cfg.enforce_eager and not self.distributed
+                           and model_cfg.head_dim == ops.HEAD_DIM_HIP)
         self._graphs: dict[int, dict] = {}
         self._graph_pool = None
         self._pin = device.type == "cuda"

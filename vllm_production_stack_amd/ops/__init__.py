@@ -120,13 +120,33 @@ def rms_norm(x, weight, eps, residual=None, out=None):
 
 
 # --------------------------------------------------------------------------- rope + cache write
+def _generic_attention(t, head_dim) -> bool:
+    """The HIP attention kernels are built for head_dim 128 (Llama-3, Mixtral).  Other head
+    sizes on a GPU (OPT-125m class test models) take the PyTorch definitions: correct, slow,
+    and announced once, never chosen for a model the kernels cover."""
+    global _warned_generic
+    if not t.is_cuda:
+        return True
+    if head_dim == HEAD_DIM_HIP:
+        return False
+    if not _warned_generic:
+        _warned_generic = True
+        import logging
+
+        logging.getLogger("vpsa.ops").warning(
+            "head_dim %d: attention runs on the generic PyTorch path (the HIP kernels cover head_dim %d)",
+            head_dim, HEAD_DIM_HIP)
+    return True
+
+
+_warned_generic = False
+
+
 def rope_and_cache(qkv, positions, slots, cos_sin, pool, layer, n_q, n_kv, head_dim, rotary=True):
-    if not qkv.is_cuda:
+    if _generic_attention(qkv, head_dim):
         return reference.rope_and_cache(qkv, positions, slots, cos_sin, pool, layer, n_q, n_kv,
                                         head_dim, rotary)
     _bf16_cuda(qkv, pool)
-    if head_dim != HEAD_DIM_HIP:
-        raise ValueError("HIP attention path is built for head_dim 128")
     assert positions.dtype == torch.int32 and (slots is None or slots.dtype == torch.int64)
     assert cos_sin.dtype == torch.float32 and cos_sin.shape[1] == head_dim
     base = pool.data_ptr() + layer * pool.stride(1) * 2
@@ -154,12 +174,10 @@ def build_prefill_tiles(q_lens, n_q, n_kv):
 
 def paged_prefill(q, out, pool, layer, block_tables, cu_q, ctx_lens, tile_seq, tile_q0, n_q, n_kv,
                   head_dim, scale):
-    if not q.is_cuda:
+    if _generic_attention(q, head_dim):
         return reference.paged_prefill(q, out, pool, layer, block_tables, cu_q, ctx_lens, n_q,
                                        n_kv, head_dim, scale)
     _bf16_cuda(q, out, pool)
-    if head_dim != HEAD_DIM_HIP:
-        raise ValueError("HIP attention path is built for head_dim 128")
     for t in (block_tables, cu_q, ctx_lens, tile_seq, tile_q0):
         assert t.dtype == torch.int32 and t.is_cuda and t.is_contiguous()
     assert tile_seq.numel() == tile_q0.numel()
@@ -185,12 +203,10 @@ def decode_num_splits(num_seqs: int, n_kv: int, max_ctx: int) -> int:
 
 def paged_decode(q, out, pool, layer, block_tables, ctx_lens, n_q, n_kv, head_dim, scale,
                  num_splits=1, ws_o=None, ws_ml=None):
-    if not q.is_cuda:
+    if _generic_attention(q, head_dim):
         return reference.paged_decode(q, out, pool, layer, block_tables, ctx_lens, n_q, n_kv,
                                       head_dim, scale)
     _bf16_cuda(q, out, pool)
-    if head_dim != HEAD_DIM_HIP:
-        raise ValueError("HIP attention path is built for head_dim 128")
     assert block_tables.dtype == torch.int32 and ctx_lens.dtype == torch.int32
     n = q.shape[0]
     assert block_tables.shape[0] >= n and ctx_lens.numel() >= n
