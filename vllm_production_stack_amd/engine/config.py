@@ -19,7 +19,7 @@ import torch
 @dataclass
 class ModelConfig:
     name: str = "tiny-llama"
-    architecture: str = "llama"  # llama | mixtral | opt
+    architecture: str = "llama"  # llama | mixtral | opt | gpt2
     vocab_size: int = 512
     hidden_size: int = 256
     intermediate_size: int = 512
@@ -36,9 +36,10 @@ class ModelConfig:
     num_experts_per_tok: int = 0
     bos_token_id: int = 1
     eos_token_id: int = 2
-    # OPT specifics
+    # OPT / GPT-2 specifics (learned positions, LayerNorm, biased projections)
     ffn_dim: int = 0
     pos_offset: int = 0
+    activation: str = "relu"  # relu (OPT) | gelu_new (GPT-2)
 
     @property
     def q_size(self) -> int:
@@ -81,6 +82,44 @@ PRESETS: dict[str, ModelConfig] = {
         intermediate_size=3072, num_layers=12, num_heads=12, num_kv_heads=12, head_dim=64,
         max_position_embeddings=2048, ffn_dim=3072, pos_offset=2, tie_word_embeddings=True,
         bos_token_id=2, eos_token_id=2),
+    # the other models the reference's tutorials and CI values name
+    "mistral-7b": ModelConfig(
+        name="mistral-7b", architecture="llama", vocab_size=32000, hidden_size=4096,
+        intermediate_size=14336, num_layers=32, num_heads=32, num_kv_heads=8, head_dim=128,
+        rope_theta=1000000.0, norm_eps=1e-5, max_position_embeddings=32768, bos_token_id=1, eos_token_id=2),
+    "llama-3-70b": ModelConfig(
+        name="llama-3-70b", architecture="llama", vocab_size=128256, hidden_size=8192,
+        intermediate_size=28672, num_layers=80, num_heads=64, num_kv_heads=8, head_dim=128,
+        rope_theta=500000.0, norm_eps=1e-5, max_position_embeddings=131072,
+        rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0,
+                      "high_freq_factor": 4.0, "original_max_position_embeddings": 8192},
+        bos_token_id=128000, eos_token_id=128009),
+    "llama-3.2-1b": ModelConfig(
+        name="llama-3.2-1b", architecture="llama", vocab_size=128256, hidden_size=2048,
+        intermediate_size=8192, num_layers=16, num_heads=32, num_kv_heads=8, head_dim=64,
+        rope_theta=500000.0, norm_eps=1e-5, max_position_embeddings=131072, tie_word_embeddings=True,
+        rope_scaling={"rope_type": "llama3", "factor": 32.0, "low_freq_factor": 1.0,
+                      "high_freq_factor": 4.0, "original_max_position_embeddings": 8192},
+        bos_token_id=128000, eos_token_id=128009),
+    "smollm2-135m": ModelConfig(
+        name="smollm2-135m", architecture="llama", vocab_size=49152, hidden_size=576,
+        intermediate_size=1536, num_layers=30, num_heads=9, num_kv_heads=3, head_dim=64,
+        rope_theta=100000.0, norm_eps=1e-5, max_position_embeddings=8192, tie_word_embeddings=True,
+        bos_token_id=1, eos_token_id=2),
+    "distilgpt2": ModelConfig(
+        name="distilgpt2", architecture="gpt2", vocab_size=50257, hidden_size=768,
+        intermediate_size=3072, num_layers=6, num_heads=12, num_kv_heads=12, head_dim=64,
+        max_position_embeddings=1024, ffn_dim=3072, pos_offset=0, tie_word_embeddings=True,
+        activation="gelu_new", bos_token_id=50256, eos_token_id=50256),
+    "gpt2": ModelConfig(
+        name="gpt2", architecture="gpt2", vocab_size=50257, hidden_size=768,
+        intermediate_size=3072, num_layers=12, num_heads=12, num_kv_heads=12, head_dim=64,
+        max_position_embeddings=1024, ffn_dim=3072, pos_offset=0, tie_word_embeddings=True,
+        activation="gelu_new", bos_token_id=50256, eos_token_id=50256),
+    "tiny-gpt2": ModelConfig(name="tiny-gpt2", architecture="gpt2", vocab_size=512, hidden_size=128,
+                             intermediate_size=256, ffn_dim=256, num_layers=2, num_heads=4,
+                             num_kv_heads=4, head_dim=32, pos_offset=0, tie_word_embeddings=True,
+                             activation="gelu_new", max_position_embeddings=2048),
     "tiny-llama": ModelConfig(name="tiny-llama"),
     "tiny-llama-gqa": ModelConfig(name="tiny-llama-gqa", num_heads=8, num_kv_heads=2,
                                   hidden_size=512, intermediate_size=1024, num_layers=3),
@@ -101,6 +140,16 @@ _ALIASES = {
     "mistralai/mixtral-8x7b-v0.1": "mixtral-8x7b",
     "mistralai/mixtral-8x7b-instruct-v0.1": "mixtral-8x7b",
     "facebook/opt-125m": "opt-125m",
+    "mistralai/mistral-7b-instruct-v0.2": "mistral-7b",
+    "mistralai/mistral-7b-v0.1": "mistral-7b",
+    "meta-llama/llama-3.3-70b-instruct": "llama-3-70b",
+    "meta-llama/llama-3.1-70b-instruct": "llama-3-70b",
+    "meta-llama/meta-llama-3-70b-instruct": "llama-3-70b",
+    "meta-llama/llama-3.2-1b-instruct": "llama-3.2-1b",
+    "meta-llama/llama-3.2-1b": "llama-3.2-1b",
+    "huggingfacetb/smollm2-135m-instruct": "smollm2-135m",
+    "distilbert/distilgpt2": "distilgpt2",
+    "openai-community/gpt2": "gpt2",
 }
 
 
@@ -117,7 +166,24 @@ def _from_hf_config(cfg: dict[str, Any], name: str) -> ModelConfig:
             max_position_embeddings=cfg.get("max_position_embeddings", 2048), pos_offset=2,
             tie_word_embeddings=True, bos_token_id=cfg.get("bos_token_id", 2),
             eos_token_id=cfg.get("eos_token_id", 2))
+    if "gpt2" in (arch + mt):
+        h = cfg["n_embd"]
+        inner = cfg.get("n_inner") or 4 * h
+        return ModelConfig(
+            name=name, architecture="gpt2", vocab_size=cfg["vocab_size"], hidden_size=h,
+            intermediate_size=inner, ffn_dim=inner, num_layers=cfg["n_layer"], num_heads=cfg["n_head"],
+            num_kv_heads=cfg["n_head"], head_dim=h // cfg["n_head"],
+            max_position_embeddings=cfg.get("n_positions", 1024), pos_offset=0, tie_word_embeddings=True,
+            activation="gelu_new", norm_eps=cfg.get("layer_norm_epsilon", 1e-5),
+            bos_token_id=cfg.get("bos_token_id", 50256), eos_token_id=cfg.get("eos_token_id", 50256))
     is_moe = "mixtral" in (arch + mt)
+    # rotary settings: top-level ``rope_theta`` / ``rope_scaling`` (checkpoints written by
+    # transformers 4.x) or one ``rope_parameters`` object (5.x)
+    rp = cfg.get("rope_parameters") or {}
+    rope_theta = cfg.get("rope_theta", rp.get("rope_theta", 10000.0))
+    rope_scaling = cfg.get("rope_scaling")
+    if rope_scaling is None and rp.get("rope_type", "default") not in ("default", None):
+        rope_scaling = {k: v for k, v in rp.items() if k != "rope_theta"}
     h, nh = cfg["hidden_size"], cfg["num_attention_heads"]
     eos = cfg.get("eos_token_id", 2)
     if isinstance(eos, list):
@@ -127,7 +193,7 @@ def _from_hf_config(cfg: dict[str, Any], name: str) -> ModelConfig:
         hidden_size=h, intermediate_size=cfg["intermediate_size"],
         num_layers=cfg["num_hidden_layers"], num_heads=nh,
         num_kv_heads=cfg.get("num_key_value_heads", nh), head_dim=cfg.get("head_dim") or h // nh,
-        rope_theta=cfg.get("rope_theta", 10000.0), rope_scaling=cfg.get("rope_scaling"),
+        rope_theta=rope_theta, rope_scaling=rope_scaling,
         norm_eps=cfg.get("rms_norm_eps", 1e-5),
         max_position_embeddings=cfg.get("max_position_embeddings", 8192),
         tie_word_embeddings=cfg.get("tie_word_embeddings", False),

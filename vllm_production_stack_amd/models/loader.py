@@ -21,7 +21,7 @@ from .transformer import LayerWeights, TransformerModel
 
 def build_model(cfg: ModelConfig, dtype: torch.dtype, device: torch.device, max_model_len: int,
                 ckpt_dir: Path | None = None, seed: int = 0, load_format: str = "auto"):
-    cls = OPTModel if cfg.architecture == "opt" else TransformerModel
+    cls = OPTModel if cfg.architecture in ("opt", "gpt2") else TransformerModel
     model = cls(cfg, dtype, device, max_model_len)
     has_weights = ckpt_dir is not None and any(Path(ckpt_dir).glob("*.safetensors"))
     if has_weights and load_format != "dummy":
@@ -49,7 +49,7 @@ def _iter_safetensors(ckpt_dir: Path):
 
 def load_hf_weights(model, ckpt_dir: Path) -> None:
     if isinstance(model, OPTModel):
-        _load_opt(model, ckpt_dir)
+        (_load_gpt2 if model.cfg.architecture == "gpt2" else _load_opt)(model, ckpt_dir)
     else:
         _load_llama(model, ckpt_dir)
 
@@ -166,3 +166,34 @@ def _load_opt(model: OPTModel, ckpt_dir: Path) -> None:
                     lw[key].copy_(t)
                 else:
                     lw[key][part * h:(part + 1) * h].copy_(t)
+
+
+def _load_gpt2(model: OPTModel, ckpt_dir: Path) -> None:
+    """GPT-2 checkpoints: ``wte / wpe / h.N.{ln_1, attn.c_attn, attn.c_proj, ln_2, mlp.c_fc,
+    mlp.c_proj} / ln_f``; the Conv1D projections store [in, out] and are transposed here."""
+    pat = re.compile(r"(?:transformer\.)?h\.(\d+)\.(.+)")
+    table = {
+        "ln_1.weight": ("ln1_w", False), "ln_1.bias": ("ln1_b", False),
+        "attn.c_attn.weight": ("wqkv", True), "attn.c_attn.bias": ("bqkv", False),
+        "attn.c_proj.weight": ("wo", True), "attn.c_proj.bias": ("bo", False),
+        "ln_2.weight": ("ln2_w", False), "ln_2.bias": ("ln2_b", False),
+        "mlp.c_fc.weight": ("fc1", True), "mlp.c_fc.bias": ("b1", False),
+        "mlp.c_proj.weight": ("fc2", True), "mlp.c_proj.bias": ("b2", False),
+    }
+    for name, t in _iter_safetensors(ckpt_dir):
+        t = t.to(model.dtype)
+        base = name.removeprefix("transformer.")
+        if base == "wte.weight":
+            model.embed.copy_(t)
+        elif base == "wpe.weight":
+            n = min(t.shape[0], model.pos_embed.shape[0])
+            model.pos_embed[:n].copy_(t[:n])
+        elif base == "ln_f.weight":
+            model.final_ln[0].copy_(t)
+        elif base == "ln_f.bias":
+            model.final_ln[1].copy_(t)
+        else:
+            m = pat.match(name)
+            if m and m.group(2) in table:
+                key, transpose = table[m.group(2)]
+                model.layers[int(m.group(1))][key].copy_(t.t() if transpose else t)

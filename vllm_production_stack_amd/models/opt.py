@@ -1,4 +1,5 @@
-"""OPT decoder (facebook/opt-125m class): learned positions, pre-LayerNorm, ReLU MLP, biases.
+"""OPT / GPT-2 decoders (facebook/opt-125m, distilgpt2 class): learned positions, pre-LayerNorm,
+biased projections, ReLU or tanh-GELU MLP.
 
 Used for the CPU plumbing configuration (router in front of small CPU replicas); it shares
 the paged KV pool and the scheduler with the Llama path and runs the PyTorch op
@@ -54,7 +55,7 @@ class OPTModel:
 
         h, f = cfg.hidden_size, cfg.ffn_dim or cfg.intermediate_size
         self.embed = rnd(cfg.vocab_size, h)
-        self.pos_embed = rnd(self.max_model_len + cfg.pos_offset, h)
+        self.pos_embed = rnd(max(self.max_model_len, 1) + cfg.pos_offset, h)
         for _ in range(cfg.num_layers):
             self.layers.append({
                 "ln1_w": ones(h), "ln1_b": zeros(h), "wqkv": rnd(3 * h, h), "bqkv": zeros(3 * h),
@@ -95,7 +96,9 @@ class OPTModel:
                                   d, self.scale)
             h = h + F.linear(out, lw["wo"], lw["bo"])
             x = reference.layer_norm(h, lw["ln2_w"], lw["ln2_b"], 1e-5)
-            h = h + F.linear(F.relu(F.linear(x, lw["fc1"], lw["b1"])), lw["fc2"], lw["b2"])
+            a = F.linear(x, lw["fc1"], lw["b1"])
+            a = F.gelu(a, approximate="tanh") if cfg.activation == "gelu_new" else F.relu(a)
+            h = h + F.linear(a, lw["fc2"], lw["b2"])
         if meta.logits_rows is not None:
             h = h.index_select(0, meta.logits_rows)
         return reference.layer_norm(h, self.final_ln[0], self.final_ln[1], 1e-5)
