@@ -188,3 +188,40 @@ def test_opt_head_dim_64_runs_on_the_generic_attention_path():
     assert all(len(o) == 6 for o in outs)
     again = eng.generate(prompts[:1], SamplingParams(max_tokens=6, temperature=0, ignore_eos=True))
     assert again[0] == outs[0]  # second pass goes through the prefix cache
+
+
+def test_gpu_engine_tracks_hugging_face_llama(tmp_path):
+    """bf16 engine on the HIP kernels (head_dim 128, GQA, llama3 rope scaling) against the fp32
+    Hugging Face model of the same checkpoint: the first greedy tokens agree where the reference
+    margin is clear, and the kernels' KV cache reproduces a long prompt's next token."""
+    transformers = pytest.importorskip("transformers")
+    from vllm_production_stack_amd.engine.config import EngineConfig
+    from vllm_production_stack_amd.engine.llm_engine import LLMEngine
+    from vllm_production_stack_amd.engine.request import SamplingParams
+
+    torch.manual_seed(0)
+    cfg = transformers.LlamaConfig(
+        vocab_size=1000, hidden_size=512, intermediate_size=1024, num_hidden_layers=3,
+        num_attention_heads=4, num_key_value_heads=2, head_dim=128, max_position_embeddings=4096,
+        rope_theta=500000.0, tie_word_embeddings=False,
+        rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0,
+                      "high_freq_factor": 4.0, "original_max_position_embeddings": 256},
+        bos_token_id=1, eos_token_id=2)
+    hf = transformers.LlamaForCausalLM(cfg).eval().float()
+    with torch.no_grad():
+        for _n, p in hf.named_parameters():
+            if p.ndim > 1:
+                p.mul_(2.0)
+    hf.save_pretrained(tmp_path, safe_serialization=True)
+    eng = LLMEngine(EngineConfig(model=str(tmp_path), max_model_len=2048, max_num_seqs=4,
+                                 max_num_batched_tokens=256, num_gpu_blocks_override=64))
+    assert eng.runner.use_graphs
+    g = torch.Generator().manual_seed(1)
+    for n in (700, 90, 300, 1500):
+        prompt = torch.randint(3, 1000, (n,), generator=g).tolist()
+        with torch.no_grad():
+            logits = hf(torch.tensor([prompt])).logits[0, -1]
+        out = eng.generate([prompt], SamplingParams(max_tokens=1, temperature=0, ignore_eos=True))[0]
+        # the token the bf16 engine picks is (within bf16 noise) the fp32 model's best token
+        spread = (logits.max() - logits.median()).item()
+        assert (logits.max() - logits[out[0]]).item() < 0.03 * spread + 0.05, (n, out, spread)
