@@ -36,6 +36,7 @@ class ModelConfig:
     num_experts_per_tok: int = 0
     bos_token_id: int = 1
     eos_token_id: int = 2
+    extra_eos_token_ids: tuple = ()  # config.json may list several end-of-sequence ids
     # OPT / GPT-2 specifics (learned positions, LayerNorm, biased projections)
     ffn_dim: int = 0
     pos_offset: int = 0
@@ -186,7 +187,9 @@ def _from_hf_config(cfg: dict[str, Any], name: str) -> ModelConfig:
         rope_scaling = {k: v for k, v in rp.items() if k != "rope_theta"}
     h, nh = cfg["hidden_size"], cfg["num_attention_heads"]
     eos = cfg.get("eos_token_id", 2)
+    extra_eos: tuple = ()
     if isinstance(eos, list):
+        extra_eos = tuple(int(x) for x in eos[1:])
         eos = eos[0]
     return ModelConfig(
         name=name, architecture="mixtral" if is_moe else "llama", vocab_size=cfg["vocab_size"],
@@ -199,7 +202,7 @@ def _from_hf_config(cfg: dict[str, Any], name: str) -> ModelConfig:
         tie_word_embeddings=cfg.get("tie_word_embeddings", False),
         num_experts=cfg.get("num_local_experts", 0),
         num_experts_per_tok=cfg.get("num_experts_per_tok", 0),
-        bos_token_id=cfg.get("bos_token_id", 1), eos_token_id=eos)
+        bos_token_id=cfg.get("bos_token_id", 1), eos_token_id=eos, extra_eos_token_ids=extra_eos)
 
 
 def resolve_model(model: str) -> tuple[ModelConfig, Path | None]:

@@ -51,6 +51,9 @@ class LLMEngine:
         self.requests: dict[str, Request] = {}
         self.eos_ids = {self.tokenizer.eos_token_id, self.model_cfg.eos_token_id} if self.ckpt_dir else {
             self.tokenizer.eos_token_id}
+        self.eos_ids |= set(getattr(self.tokenizer, "eos_token_ids", ()))
+        if self.ckpt_dir:
+            self.eos_ids |= set(self.model_cfg.extra_eos_token_ids)
         self.lora_manager = None
         self.step_count = 0
         # coarse step-loop profile (seconds), read by /debug/stats and the benchmark

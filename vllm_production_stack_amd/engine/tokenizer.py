@@ -20,11 +20,48 @@ _SPECIALS = ["<|begin_of_text|>", "<|end_of_text|>", "<|start_header_id|>", "<|e
              "<|eot_id|>", "<|pad|>", "<|python_tag|>", "<|eom_id|>"]
 
 
+_TEMPLATES: dict[str, object] = {}
+
+
+def _compile_template(source: str):
+    """Chat templates are written against the environment Hugging Face renders them in: sandboxed,
+    ``trim_blocks`` + ``lstrip_blocks``, loop controls, ``raise_exception``, ``strftime_now`` and a
+    ``tojson`` that keeps non-ASCII text.  Whitespace handling is part of the prompt, so the
+    environment has to match exactly."""
+    tpl = _TEMPLATES.get(source)
+    if tpl is None:
+        import datetime
+
+        import jinja2
+        import jinja2.ext
+        import jinja2.sandbox
+
+        env = jinja2.sandbox.ImmutableSandboxedEnvironment(
+            trim_blocks=True, lstrip_blocks=True, extensions=[jinja2.ext.loopcontrols])
+
+        def raise_exception(message):
+            raise jinja2.exceptions.TemplateError(message)
+
+        def tojson(x, ensure_ascii=False, indent=None, separators=None, sort_keys=False):
+            return json.dumps(x, ensure_ascii=ensure_ascii, indent=indent, separators=separators,
+                              sort_keys=sort_keys)
+
+        env.filters["tojson"] = tojson
+        env.globals["raise_exception"] = raise_exception
+        env.globals["strftime_now"] = lambda fmt: datetime.datetime.now().strftime(fmt)
+        tpl = env.from_string(source)
+        _TEMPLATES[source] = tpl
+    return tpl
+
+
 class BaseTokenizer:
     eos_token_id: int = 2
     bos_token_id: int | None = 1
     vocab_size: int = 0
     chat_template: str | None = None
+    # special-token strings handed to the chat template (a checkpoint's tokenizer overrides them)
+    bos_token: str = "<|begin_of_text|>"
+    eos_token: str = "<|eot_id|>"
 
     def encode(self, text: str, add_special_tokens: bool = True) -> list[int]:
         raise NotImplementedError
@@ -45,16 +82,9 @@ class BaseTokenizer:
     def render_chat(self, messages: list[dict], add_generation_prompt: bool = True,
                     tools: list | None = None) -> str:
         if self.chat_template:
-            try:
-                import jinja2
-
-                env = jinja2.Environment()
-                env.globals["raise_exception"] = lambda m: (_ for _ in ()).throw(ValueError(m))
-                return env.from_string(self.chat_template).render(
-                    messages=messages, add_generation_prompt=add_generation_prompt, tools=tools,
-                    bos_token="<|begin_of_text|>", eos_token="<|eot_id|>")
-            except ImportError:
-                pass
+            return _compile_template(self.chat_template).render(
+                messages=messages, add_generation_prompt=add_generation_prompt, tools=tools,
+                bos_token=self.bos_token, eos_token=self.eos_token)
         out = ["<|begin_of_text|>"]
         if tools:
             out.append("<|start_header_id|> system <|end_header_id|> "
@@ -187,28 +217,44 @@ class HFTokenizer(BaseTokenizer):
         if (path / "tokenizer_config.json").exists():
             with open(path / "tokenizer_config.json") as f:
                 cfg = json.load(f)
-        self.chat_template = cfg.get("chat_template")
+        tpl = cfg.get("chat_template")
+        if isinstance(tpl, list):  # named templates: [{"name": ..., "template": ...}]
+            named = {t.get("name"): t.get("template") for t in tpl if isinstance(t, dict)}
+            tpl = named.get("default") or next(iter(named.values()), None)
+        if (path / "chat_template.jinja").exists():  # newer checkpoints keep it in its own file
+            tpl = (path / "chat_template.jinja").read_text()
+        self.chat_template = tpl
 
-        def tok_id(key, default):
+        def tok_str(key):
             t = cfg.get(key)
             if isinstance(t, dict):
                 t = t.get("content")
-            if isinstance(t, str):
+            return t if isinstance(t, str) else None
+
+        def tok_id(key, default):
+            t = tok_str(key)
+            if t is not None:
                 i = self._tok.token_to_id(t)
                 if i is not None:
                     return i
             return default
 
+        self.bos_token = tok_str("bos_token") or ""
+        self.eos_token = tok_str("eos_token") or ""
         self.bos_token_id = tok_id("bos_token", None)
         self.eos_token_id = tok_id("eos_token", 2)
+        # every id that ends generation (generation_config may list several, e.g. end-of-text
+        # and end-of-turn); eos_token_id stays the tokenizer's own when it has one
+        self.eos_token_ids: set[int] = {self.eos_token_id}
         gen = path / "generation_config.json"
         if gen.exists():
             with open(gen) as f:
                 e = json.load(f).get("eos_token_id")
-            if isinstance(e, list):
-                e = e[0]
-            if isinstance(e, int):
-                self.eos_token_id = e
+            ids = e if isinstance(e, list) else [e]
+            ids = [i for i in ids if isinstance(i, int)]
+            self.eos_token_ids.update(ids)
+            if ids and tok_str("eos_token") is None:
+                self.eos_token_id = ids[0]
 
     def encode(self, text: str, add_special_tokens: bool = True) -> list[int]:
         return self._tok.encode(text, add_special_tokens=add_special_tokens).ids
