@@ -97,7 +97,8 @@ class LoRAManager:
         r = int(cfg.get("r", 8))
         if r > self.max_rank:
             raise ValueError(f"adapter rank {r} exceeds --max-lora-rank {self.max_rank}")
-        scale = float(cfg.get("lora_alpha", r)) / r
+        alpha = float(cfg.get("lora_alpha", r))
+        scale = alpha / (r ** 0.5) if cfg.get("use_rslora") else alpha / r  # rank-stabilised variant
         slot = free[0]
         st_file = p / "adapter_model.safetensors"
         if st_file.exists():
