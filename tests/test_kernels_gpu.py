@@ -173,6 +173,62 @@ def test_silu_and_mul():
                                atol=2e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("m", [1, 7, 16, 17, 40, 64])
+@pytest.mark.parametrize("n,k,bias", [(6144, 4096, False), (4096, 14336, False), (1536, 1024, True),
+                                      (4096, 512, True)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_skinny_linear_matches_fp32(m, n, k, bias, variant):
+    """Decode-batch projection kernel against the fp32 product of the same bf16 operands."""
+    torch.manual_seed(m * 131 + n)
+    x = torch.randn(m, k, device=DEV).to(BF)
+    w = (torch.randn(n, k, device=DEV) * 0.03).to(BF)
+    b = torch.randn(n, device=DEV).to(BF) if bias else None
+    prev = ops.set_gemm_variant(variant)
+    try:
+        got = ops._skinny(x, w, b, False)
+    finally:
+        ops.set_gemm_variant(prev)
+    assert got is not None, "shape was expected to be tiled by the kernel"
+    want = torch.nn.functional.linear(x.float(), w.float(), None if b is None else b.float())
+    err = (got.float() - want).abs().max().item() / want.abs().max().item()
+    assert err < 1e-2, err
+
+
+def test_skinny_linear_strided_rows_and_fallback():
+    torch.manual_seed(3)
+    base = torch.randn(9, 2 * 4096, device=DEV).to(BF)
+    x = base[:, :4096]  # row stride 8192
+    w = (torch.randn(2048, 4096, device=DEV) * 0.03).to(BF)
+    want = torch.nn.functional.linear(x.float(), w.float())
+    got = ops._skinny(x, w, None, False)
+    assert (got.float() - want).abs().max().item() / want.abs().max().item() < 1e-2
+    # a reduction length the kernel does not tile takes the library path, same answer
+    w2 = (torch.randn(2048, 768, device=DEV) * 0.03).to(BF)
+    x2 = torch.randn(9, 768, device=DEV).to(BF)
+    assert ops._skinny(x2, w2, None, False) is None
+    want2 = torch.nn.functional.linear(x2.float(), w2.float())
+    assert (ops.linear(x2, w2).float() - want2).abs().max().item() / want2.abs().max().item() < 1e-2
+
+
+@pytest.mark.parametrize("m", [1, 16, 33, 64])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_skinny_gate_up_silu_matches_fp32(m, variant):
+    torch.manual_seed(m)
+    inter, k = 14336, 4096
+    x = torch.randn(m, k, device=DEV).to(BF)
+    w = (torch.randn(2 * inter, k, device=DEV) * 0.02).to(BF)
+    prev = ops.set_gemm_variant(variant)
+    try:
+        got = ops._skinny(x, w, None, True)
+    finally:
+        ops.set_gemm_variant(prev)
+    assert got is not None and got.shape == (m, inter)
+    gu = torch.nn.functional.linear(x.float(), w.float())
+    want = torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:]
+    err = (got.float() - want).abs().max().item() / want.abs().max().item()
+    assert err < 1e-2, err
+
+
 def test_argmax():
     torch.manual_seed(14)
     logits = torch.randn(19, 128256, device=DEV).to(BF)

@@ -2,7 +2,9 @@
 
 Functional style: weights are plain tensors created directly on the target device (bf16)
 and every hot op goes through ``ops`` (hand-written gfx950 kernels on the GPU); the dense
-projections are library GEMMs on the matrix cores (``F.linear`` -> hipBLASLt).
+projections are library GEMMs on the matrix cores (``F.linear`` -> hipBLASLt), except the
+small-batch decode projections that ``ops.linear`` / ``ops.gate_up_silu`` route to the
+weight-streaming MFMA kernels of ``csrc/kernels/gemm.hip``.
 Tensor parallelism: QKV / gate-up are column-sharded by head / channel, O / down are
 row-sharded and followed by one all-reduce each; the LM head is vocab-sharded.
 Pipeline parallelism: a stage holds a contiguous run of layers (and the KV pool slices of
@@ -227,17 +229,20 @@ class TransformerModel:
                 x = ops.rms_norm(h, lw.ln1, cfg.norm_eps)
             else:
                 x = ops.rms_norm(h, lw.ln1, cfg.norm_eps, residual)
-            qkv = self._lora("qkv", gl, x, F.linear(x, lw.wqkv), meta)
+            qkv = self._lora("qkv", gl, x, ops.linear(x, lw.wqkv), meta)
             attn = self._attention(qkv, pool, li, meta)
-            h = self._lora("o", gl, attn, F.linear(attn, lw.wo), meta)
+            h = self._lora("o", gl, attn, ops.linear(attn, lw.wo), meta)
             h = tp_all_reduce(h)
             x = ops.rms_norm(h, lw.ln2, cfg.norm_eps, residual)
             if cfg.num_experts > 0:
                 h = self._moe(x, lw, decode_only)
             else:
-                gu = self._lora("gate_up", gl, x, F.linear(x, lw.w_gate_up), meta)
-                act = ops.silu_and_mul(gu)
-                h = self._lora("down", gl, act, F.linear(act, lw.w_down), meta)
+                if self.lora is not None and meta.lora_slots is not None:
+                    gu = self._lora("gate_up", gl, x, F.linear(x, lw.w_gate_up), meta)
+                    act = ops.silu_and_mul(gu)
+                else:
+                    act = ops.gate_up_silu(x, lw.w_gate_up)
+                h = self._lora("down", gl, act, ops.linear(act, lw.w_down), meta)
             h = tp_all_reduce(h)
         if not pp.is_last:
             pp_send(h, pp.next)

@@ -32,6 +32,7 @@ def _kernels():
             "vpsa_kv_scatter_pages", "vpsa_cachegen_encode", "vpsa_cachegen_decode",
             "vpsa_moe_topk_softmax", "vpsa_moe_align", "vpsa_moe_permute", "vpsa_moe_combine",
             "vpsa_moe_gemv", "vpsa_moe_mfma", "vpsa_lora_shrink", "vpsa_lora_expand",
+            "vpsa_skinny_gemm", "vpsa_hbm_read_probe", "vpsa_set_gemm_variant",
         ):
             getattr(lib, name).restype = c_int
         if os.environ.get("VPSA_PREFILL_VARIANT"):  # pin one prefill kernel for A/B runs
@@ -222,6 +223,78 @@ def paged_decode(q, out, pool, layer, block_tables, ctx_lens, n_q, n_kv, head_di
         c_int(block_tables.stride(0)), _p(ctx_lens), _p(ws_o), _p(ws_ml), c_int(n), c_int(n_q),
         c_int(n_kv), c_int(num_splits), c_float(scale), _stream())
     _check(rc, "paged_decode")
+
+
+# --------------------------------------------------------------------------- projections
+SKINNY_MAX_ROWS = 64
+_skinny_enabled = os.environ.get("VPSA_SKINNY_GEMM", "1") != "0"
+
+
+def set_skinny_gemm(on: bool) -> bool:
+    """Switch the decode-batch projection kernels on or off (A/B timing); returns the old value."""
+    global _skinny_enabled
+    old, _skinny_enabled = _skinny_enabled, bool(on)
+    return old
+
+
+def set_gemm_variant(v: int) -> int:
+    """Tiling knobs of the decode-batch projection kernel (bit 0: eight loads per operand in
+    flight instead of four, bit 1: four waves per workgroup); returns the previous value."""
+    return int(_kernels().vpsa_set_gemm_variant(c_int(v)))
+
+
+def _skinny(x2, w, bias, pair):
+    n_out = w.shape[0] // 2 if pair else w.shape[0]
+    out = torch.empty((x2.shape[0], n_out), dtype=x2.dtype, device=x2.device)
+    rc = _kernels().vpsa_skinny_gemm(_p(x2), c_long(x2.stride(0)), _p(w), _p(bias), _p(out),
+                                     c_long(out.stride(0)), c_int(x2.shape[0]), c_int(w.shape[0]),
+                                     c_int(w.shape[1]), c_int(1 if pair else 0), _stream())
+    return out if rc == 0 else None
+
+
+def _skinny_ok(x, w, bias):
+    return (_skinny_enabled and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+            and w.is_contiguous() and x.dim() == 2 and 0 < x.shape[0] <= SKINNY_MAX_ROWS
+            and x.stride(1) == 1 and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous())))
+
+
+# Measured on MI355X (profiles/gemm_micro_graph.jsonl, HIP-graph replay, Llama-3-8B shapes): the
+# kernel beats the library GEMM for square-ish projections (o-proj: 9.7 vs 14.9 us at 1-8 rows,
+# 11.3 vs 15.0 at 16) and for the fused SwiGLU up-projection up to 8 rows (55.7-58.2 us vs
+# 60.3-61.4 for GEMM + activation); from ~24 rows on the library wins everywhere.
+SKINNY_PLAIN_MAX_ROWS = 16
+SKINNY_PLAIN_MAX_WEIGHT_ELEMS = 4096 * 4096 + 1
+SKINNY_PAIR_MAX_ROWS = 8
+
+
+def linear(x, w, bias=None):
+    """y = x @ w.T (+ bias).  Small decode batches against a square-ish weight run the
+    weight-streaming MFMA kernel of ``csrc/kernels/gemm.hip``; everything else goes to the
+    library GEMM (hipBLASLt)."""
+    if (x.dim() == 2 and x.shape[0] <= SKINNY_PLAIN_MAX_ROWS and w.numel() < SKINNY_PLAIN_MAX_WEIGHT_ELEMS
+            and _skinny_ok(x, w, bias)):
+        y = _skinny(x, w, bias, False)
+        if y is not None:
+            return y
+    return torch.nn.functional.linear(x, w, bias)
+
+
+def gate_up_silu(x, w_gate_up):
+    """silu(x @ Wg.T) * (x @ Wu.T) for ``w_gate_up = [Wg; Wu]``: fused in one kernel for
+    decode batches, library GEMM + activation kernel otherwise."""
+    if x.dim() == 2 and x.shape[0] <= SKINNY_PAIR_MAX_ROWS and _skinny_ok(x, w_gate_up, None):
+        y = _skinny(x, w_gate_up, None, True)
+        if y is not None:
+            return y
+    return silu_and_mul(torch.nn.functional.linear(x, w_gate_up))
+
+
+def hbm_read_probe(buf, blocks=2048):
+    """Launch the read-bandwidth probe over ``buf`` (timing is the caller's)."""
+    sink = torch.zeros(1, dtype=torch.int32, device=buf.device)
+    rc = _kernels().vpsa_hbm_read_probe(_p(buf), c_long(buf.numel() * buf.element_size()), _p(sink),
+                                        c_int(blocks), _stream())
+    _check(rc, "hbm_read_probe")
 
 
 # --------------------------------------------------------------------------- MLP / sampling
