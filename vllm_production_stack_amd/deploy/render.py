@@ -483,6 +483,7 @@ def render_router(values: dict, release: str, namespace: str) -> list[dict]:
         ref = (_secret_ref(f"{release}-secrets", "vllmApiKey") if isinstance(key, str)
                else _secret_ref(key["secretName"], key["secretKey"]))
         env.append({"name": "VLLM_API_KEY", **ref})
+    env.extend(copy.deepcopy(rs.get("env") or []))  # e.g. OTEL_* for router spans
     probe = {"httpGet": {"path": "/health", "port": port}, "periodSeconds": 5, "failureThreshold": 3}
     container: dict[str, Any] = {
         "name": "router-container", "image": f"{rs['repository']}:{rs['tag']}",

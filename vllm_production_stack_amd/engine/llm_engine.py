@@ -163,7 +163,8 @@ class LLMEngine:
                 self.metrics.e2e.observe(t - req.arrival)
                 self.metrics.success.inc()
             outputs.append(StepOutput(req.request_id, [tok], reason is not None, reason,
-                                      req.prompt_len, len(req.output_ids), req.num_cached_tokens + req.num_external_tokens))
+                                      req.prompt_len, len(req.output_ids), req.num_cached_tokens + req.num_external_tokens,
+                                      (req.first_scheduled - req.arrival) if req.first_scheduled else 0.0))
         if self.connector is not None and fresh_pages:
             self.connector.store_pages(fresh_pages)
         self.metrics.update_scheduler(self.scheduler, self.bm)

@@ -99,3 +99,4 @@ class StepOutput:
     num_prompt_tokens: int = 0
     num_output_tokens: int = 0
     num_cached_tokens: int = 0
+    queue_time: float = 0.0  # seconds between arrival and the first scheduled step

@@ -18,6 +18,7 @@ import uuid
 from aiohttp import web
 
 from .. import __version__
+from ..tracing import Tracer
 from .async_engine import AsyncLLMEngine
 from .request import SamplingParams
 from .tokenizer import IncrementalDetokenizer
@@ -93,6 +94,37 @@ class EngineServer:
         r.add_post("/kv/rccl_init", self.kv_rccl_init)
         r.add_post("/kv/rccl_recv", self.kv_rccl_recv)
         self._receiver = None
+        # spans go to the collector named by the standard OTEL_* environment; off without it
+        self.tracer = Tracer.from_env("vpsa-engine")
+        self.app.on_cleanup.append(self._close_tracer)
+
+    async def _close_tracer(self, app):
+        await asyncio.get_running_loop().run_in_executor(None, self.tracer.shutdown)
+
+    def _request_span(self, request, rid, ids, params, model):
+        """Server span of one generation request, child of the caller's ``traceparent``."""
+        span = self.tracer.start_span("llm_request", request.headers.get("traceparent"))
+        if span.trace_id:
+            span.set("gen_ai.request.id", rid).set("gen_ai.response.model", model)
+            span.set("gen_ai.request.max_tokens", params.max_tokens)
+            span.set("gen_ai.request.temperature", float(params.temperature))
+            span.set("gen_ai.request.top_p", float(params.top_p))
+            span.set("gen_ai.usage.prompt_tokens", len(ids)).set("http.route", request.path)
+        return span
+
+    @staticmethod
+    def _end_span(span, t0, t_first, n_out, cached, queue_time, reason, error=None):
+        if not span.trace_id:
+            return
+        now = time.time()
+        span.set("gen_ai.usage.completion_tokens", n_out).set("gen_ai.usage.cached_tokens", cached)
+        span.set("gen_ai.latency.time_in_queue", float(queue_time))
+        if t_first is not None:
+            span.set("gen_ai.latency.time_to_first_token", t_first - t0)
+        span.set("gen_ai.latency.e2e", now - t0).set("gen_ai.response.finish_reason", reason)
+        if error:
+            span.error(error)
+        span.end()
 
     # ------------------------------------------------------------------ middleware
     @web.middleware
@@ -287,15 +319,27 @@ class EngineServer:
         return web.Response(text=f"Success: LoRA adapter '{name}' removed successfully.")
 
     # ------------------------------------------------------------------ generation core
-    async def _run_text(self, rid, ids, params, lora, kvp=None):
+    async def _run_text(self, rid, ids, params, lora, kvp=None, span=None):
         """Collect a whole generation. -> (text, out_ids, finish_reason, usage dict)"""
         detok = IncrementalDetokenizer(self.engine.tokenizer)
+        t0 = time.time()
+        try:
+            return await self._collect(rid, ids, params, lora, kvp, span, detok, t0)
+        except BaseException as e:
+            if span is not None:
+                self._end_span(span, t0, None, 0, 0, 0.0, "error", error=repr(e))
+            raise
+
+    async def _collect(self, rid, ids, params, lora, kvp, span, detok, t0):
         text = ""
         out_ids: list[int] = []
         reason = None
         last = None
+        t_first = None
         async for so in self.ae.generate(rid, ids, params, lora, kvp):
             last = so
+            if t_first is None and so.new_token_ids:
+                t_first = time.time()
             new = [t for t in so.new_token_ids if not (so.finished and so.finish_reason == "stop"
                                                        and t in self.engine.eos_ids)]
             out_ids.extend(so.new_token_ids)
@@ -311,6 +355,9 @@ class EngineServer:
                  "total_tokens": len(ids) + len(out_ids)}
         if last is not None and last.num_cached_tokens:
             usage["prompt_tokens_details"] = {"cached_tokens": last.num_cached_tokens}
+        if span is not None:
+            self._end_span(span, t0, t_first, len(out_ids), last.num_cached_tokens if last else 0,
+                           last.queue_time if last else 0.0, reason or "stop")
         return text, out_ids, reason or "stop", usage
 
     @staticmethod
@@ -324,6 +371,8 @@ class EngineServer:
         return best
 
     async def _stream(self, request, rid, ids, params, lora, kind, model, include_usage, kvp=None):
+        span = self._request_span(request, rid, ids, params, model)
+        t0, t_first, queue_time, failure = time.time(), None, 0.0, None
         resp = web.StreamResponse(status=200, headers={
             "Content-Type": "text/event-stream", "Cache-Control": "no-cache", "X-Request-Id": rid})
         await resp.prepare(request)
@@ -364,6 +413,9 @@ class EngineServer:
             async for so in self.ae.generate(rid, ids, params, lora, kvp):
                 n_out += len(so.new_token_ids)
                 cached = so.num_cached_tokens
+                queue_time = so.queue_time
+                if t_first is None and so.new_token_ids:
+                    t_first = time.time()
                 new = [t for t in so.new_token_ids
                        if not (so.finished and so.finish_reason == "stop" and t in self.engine.eos_ids)]
                 text += detok.push(new)
@@ -390,10 +442,13 @@ class EngineServer:
                 await resp.write(chunk(usage=usage, choices=False))
             await resp.write(b"data: [DONE]\n\n")
         except (ConnectionResetError, asyncio.CancelledError):
+            self._end_span(span, t0, t_first, n_out, cached, queue_time, "abort", error="client disconnected")
             raise
         except Exception as e:
             log.exception("stream failed")
+            failure = repr(e)
             await resp.write(b"data: " + json.dumps({"error": str(e)}).encode() + b"\n\n")
+        self._end_span(span, t0, t_first, n_out, cached, queue_time, reason or "stop", error=failure)
         await resp.write_eof()
         return resp
 
@@ -442,7 +497,8 @@ class EngineServer:
             inc = bool((body.get("stream_options") or {}).get("include_usage"))
             return await self._stream(request, rid, ids, params, lora, "chat", model, inc, kvp)
         try:
-            text, out_ids, reason, usage = await self._run_text(rid, ids, params, lora, kvp)
+            span = self._request_span(request, rid, ids, params, model)
+            text, out_ids, reason, usage = await self._run_text(rid, ids, params, lora, kvp, span)
         except ValueError as e:
             return _err(400, str(e))
         message = {"role": "assistant", "content": text}
@@ -468,7 +524,8 @@ class EngineServer:
             inc = bool((body.get("stream_options") or {}).get("include_usage"))
             return await self._stream(request, rid, ids, params, lora, "completion", model, inc, kvp)
         try:
-            text, out_ids, reason, usage = await self._run_text(rid, ids, params, lora, kvp)
+            span = self._request_span(request, rid, ids, params, model)
+            text, out_ids, reason, usage = await self._run_text(rid, ids, params, lora, kvp, span)
         except ValueError as e:
             return _err(400, str(e))
         if body.get("echo"):

@@ -19,7 +19,7 @@ import time
 import aiohttp
 from aiohttp import web
 
-from .. import __version__
+from .. import __version__, tracing
 from . import metrics as router_metrics
 from .batches import initialize_batch_processor
 from .callbacks import load_callbacks
@@ -59,6 +59,8 @@ class RouterState:
         self.pii_guard = None
         self.tasks: list[asyncio.Task] = []
         self.start_time = time.time()
+        # request spans go to the collector named by the OTEL_* environment (off without it)
+        self.tracer = tracing.Tracer.from_env("vpsa-router")
 
 
 STATE_KEY = web.AppKey("state", RouterState)
@@ -503,6 +505,7 @@ async def shutdown_all(state: RouterState) -> None:
         await state.service_discovery.close()
     if state.client is not None:
         await state.client.close()
+    await asyncio.get_running_loop().run_in_executor(None, state.tracer.shutdown)
 
 
 def create_app(args: argparse.Namespace) -> web.Application:

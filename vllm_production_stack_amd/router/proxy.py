@@ -22,6 +22,7 @@ import uuid
 import aiohttp
 from aiohttp import web
 
+from .. import tracing
 from .log import init_logger
 from .utils import dumps
 
@@ -54,7 +55,7 @@ def _session_id(state, request) -> str | None:
 
 async def _relay(state, request: web.Request, method: str, url: str, headers: dict, body,
                  server_url: str, request_id: str, want_body: bool,
-                 media_type: str | None = None) -> tuple[web.StreamResponse, bytes | None]:
+                 media_type: str | None = None, span=None) -> tuple[web.StreamResponse, bytes | None]:
     """Stream the backend response to the client; returns (response, accumulated body?)."""
     mon = state.request_stats_monitor
     mon.on_new_request(server_url, request_id, time.time())
@@ -77,6 +78,8 @@ async def _relay(state, request: web.Request, method: str, url: str, headers: di
                 if first:
                     mon.on_request_response(server_url, request_id, now)
                     first = False
+                    if span is not None:
+                        span.event("first_chunk")
                 else:
                     mon.on_request_chunk(server_url, request_id, now)
                 if acc is not None:
@@ -90,11 +93,34 @@ async def _relay(state, request: web.Request, method: str, url: str, headers: di
     return resp, (bytes(acc) if acc is not None else None)
 
 
+async def _traced(state, request: web.Request, endpoint: str, handler) -> web.StreamResponse:
+    """Run ``handler(state, request, endpoint, span)`` inside the router's server span (a child
+    of the caller's ``traceparent``; the engines' spans become children of it)."""
+    tracer = getattr(state, "tracer", None) or tracing.DISABLED
+    span = tracer.start_span("router " + endpoint, request.headers.get("traceparent"))
+    span.set("http.route", endpoint).set("http.method", request.method)
+    try:
+        resp = await handler(state, request, endpoint, span)
+        span.set("http.status_code", resp.status)
+        if resp.status >= 500:
+            span.error(f"HTTP {resp.status}")
+        return resp
+    except BaseException as e:
+        span.error(repr(e))
+        raise
+    finally:
+        span.end()
+
+
 async def route_general_request(state, request: web.Request, endpoint: str) -> web.StreamResponse:
     from .routing import DisaggregatedPrefillRouter
 
     if isinstance(state.router, DisaggregatedPrefillRouter):
-        return await route_disaggregated_prefill_request(state, request, endpoint)
+        return await _traced(state, request, endpoint, _route_disaggregated_prefill)
+    return await _traced(state, request, endpoint, _route_general)
+
+
+async def _route_general(state, request: web.Request, endpoint: str, span) -> web.StreamResponse:
     in_router_time = time.time()
     request_id = request.headers.get("X-Request-Id") or str(uuid.uuid4())
     body = await request.read()
@@ -157,10 +183,16 @@ async def route_general_request(state, request: web.Request, endpoint: str) -> w
         logger.info("Routing request %s with session id %s to %s at %s, process time = %.4f",
                     request_id, _session_id(state, request), server_url, curr,
                     curr - in_router_time)
+        span.set("vpsa.request_id", request_id).set("vpsa.model", requested_model)
+        span.set("vpsa.routing_logic", type(state.router).__name__).set("vpsa.endpoint", server_url)
+        span.set("vpsa.routing_seconds", curr - in_router_time)
+        fwd = _fwd_headers(request, body)
+        if span.traceparent:
+            fwd["traceparent"] = span.traceparent
         try:
             resp, full = await _relay(state, request, request.method, server_url + endpoint,
-                                      _fwd_headers(request, body), body, server_url, request_id,
-                                      want_body, "text/event-stream")
+                                      fwd, body, server_url, request_id,
+                                      want_body, "text/event-stream", span)
         except aiohttp.ClientConnectorError as e:
             # nothing was sent to the client yet: another endpoint may take the request
             last_err = e
@@ -181,6 +213,11 @@ async def route_general_request(state, request: web.Request, endpoint: str) -> w
 # ------------------------------------------------------------------ disaggregated prefill
 async def route_disaggregated_prefill_request(state, request: web.Request,
                                               endpoint: str) -> web.StreamResponse:
+    return await _traced(state, request, endpoint, _route_disaggregated_prefill)
+
+
+async def _route_disaggregated_prefill(state, request: web.Request, endpoint: str,
+                                       span) -> web.StreamResponse:
     in_router_time = time.time()
     request_id = request.headers.get("X-Request-Id") or str(uuid.uuid4())
     try:
@@ -206,6 +243,10 @@ async def route_disaggregated_prefill_request(state, request: web.Request,
     headers = {"Content-Type": "application/json", "X-Request-Id": request_id}
     if api_key:
         headers["Authorization"] = f"Bearer {api_key}"
+    if span.traceparent:
+        headers["traceparent"] = span.traceparent
+    span.set("vpsa.request_id", request_id).set("vpsa.prefill_endpoint", prefill_url)
+    span.set("vpsa.endpoint", decode_url).set("vpsa.routing_logic", "disaggregated_prefill")
     sid = _session_id(state, request)
     mon = state.request_stats_monitor
 
@@ -244,6 +285,7 @@ async def route_disaggregated_prefill_request(state, request: web.Request,
     mon.on_request_response(prefill_url, request_id, et)
     mon.on_request_complete(prefill_url, request_id, et)
     logger.info("%s prefill time (TTFT): %.4f", request_id, et - st)
+    span.event("prefill_done", seconds=et - st)
     logger.info("Routing request %s with session id %s to %s at %s, process time = %.4f",
                 request_id, sid, prefill_url, et, et - in_router_time)
 
@@ -259,7 +301,7 @@ async def route_disaggregated_prefill_request(state, request: web.Request,
     try:
         resp, _ = await _relay(state, request, "POST", decode_url + endpoint,
                                {**headers, "Content-Length": str(len(body))}, body, decode_url,
-                               request_id, False, "application/json")
+                               request_id, False, "application/json", span)
         return resp
     except aiohttp.ClientError as e:
         return web.json_response(
