@@ -232,3 +232,64 @@ def _validate(schema, value, path="values"):
 def test_values_match_schema(path):
     schema = json.loads((ROOT / "deploy/helm/values.schema.json").read_text())
     _validate(schema, yaml.safe_load(path.read_text()) or {})
+
+
+def test_operator_kustomize_tree_is_consistent():
+    """deploy/operator/config: every kustomization resolves, the manager's flags exist in the
+    operator binary's CLI, and its ClusterRole covers what the reconcilers create."""
+    import re
+
+    cfg = ROOT / "deploy" / "operator" / "config"
+    kustomizations = list(cfg.rglob("kustomization.yaml"))
+    assert len(kustomizations) >= 6
+    for k in kustomizations:
+        doc = yaml.safe_load(k.read_text())
+        assert doc["kind"] == "Kustomization"
+        for res in doc["resources"]:
+            target = (k.parent / res).resolve()
+            assert target.exists(), f"{k}: {res} does not exist"
+            if target.is_dir():
+                assert (target / "kustomization.yaml").exists()
+    dep = yaml.safe_load((cfg / "manager" / "deployment.yaml").read_text())
+    manager = dep["spec"]["template"]["spec"]["containers"][0]
+    src = (ROOT / "csrc" / "operator" / "operator_main.cpp").read_text()
+    for flag in [a for a in manager["args"] if a.startswith("--")]:
+        assert f'"{flag}"' in src, f"operator has no flag {flag}"
+    assert manager["args"][0] == "run" and manager["livenessProbe"]["httpGet"]["path"] == "/healthz"
+    assert dep["spec"]["template"]["spec"]["serviceAccountName"] == "controller-manager"
+    role = yaml.safe_load((cfg / "rbac" / "role.yaml").read_text())
+    granted = {(g, r) for rule in role["rules"] for g in rule["apiGroups"] for r in rule["resources"]}
+    for need in [("apps", "deployments"), ("", "services"), ("", "persistentvolumeclaims"),
+                 ("", "serviceaccounts"), ("rbac.authorization.k8s.io", "roles"),
+                 ("rbac.authorization.k8s.io", "rolebindings"), ("", "pods"),
+                 ("production-stack.vllm.ai", "vllmruntimes"), ("production-stack.vllm.ai", "loraadapters/status")]:
+        assert need in granted, need
+    # the generator reproduces the checked-in tree
+    import subprocess, sys, filecmp, shutil, tempfile
+    before = tempfile.mkdtemp()
+    try:
+        shutil.copytree(cfg, before, dirs_exist_ok=True)
+        subprocess.run([sys.executable, str(ROOT / "tools" / "gen_operator_config.py")], check=True)
+        cmp = filecmp.dircmp(before, cfg)
+        assert not cmp.diff_files and not cmp.left_only and not cmp.right_only
+    finally:
+        shutil.rmtree(before)
+
+
+def test_chart_readme_documents_every_schema_key():
+    import json
+
+    schema = json.loads((ROOT / "deploy" / "helm" / "values.schema.json").read_text())
+    readme = (ROOT / "deploy" / "helm" / "README.md").read_text()
+    missing = []
+    for section in ("servingEngineSpec", "routerSpec", "cacheserverSpec"):
+        for key in schema["properties"][section]["properties"]:
+            if key not in readme:
+                missing.append(f"{section}.{key}")
+    for key, sub in schema["properties"]["servingEngineSpec"]["properties"]["modelSpec"]["items"]["properties"].items():
+        if key not in readme:
+            missing.append(f"modelSpec.{key}")
+        for k2 in (sub.get("properties") or {}) if key in ("vllmConfig", "lmcacheConfig") else ():
+            if k2 not in readme and k2[0].upper() + k2[1:] not in readme:
+                missing.append(f"modelSpec.{key}.{k2}")
+    assert not missing, missing
