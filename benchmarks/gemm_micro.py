@@ -58,7 +58,7 @@ def timed(fn, iters, graph=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", default="1,4,8,16,24,32,40,64")
-    ap.add_argument("--variants", default="0,1")
+    ap.add_argument("--variants", default="0")
     ap.add_argument("--shapes", default=",".join(SHAPES))
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -102,6 +102,20 @@ def main():
                 row[f"v{v}_us"] = round(t * 1e6, 1)
                 row[f"v{v}_TB_per_s"] = round(wbytes / t / 1e12, 2)
                 row[f"v{v}_rel_err"] = round(err, 5)
+            for v in (0, 4):  # streaming kernel: chunks of 128 / 256 elements
+                ops.set_gemm_variant(v)
+
+                def stream(i=0):
+                    return ops._stream_gemm(x, ws[i % copies], None, pair)
+
+                got = stream(0)
+                if got is None:
+                    continue
+                err = float((got.float() - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
+                t = timed(stream, iters)
+                row[f"s{v}_us"] = round(t * 1e6, 1)
+                row[f"s{v}_TB_per_s"] = round(wbytes / t / 1e12, 2)
+                row[f"s{v}_rel_err"] = round(err, 5)
             ops.set_gemm_variant(0)
             print(json.dumps(row), flush=True)
         del ws

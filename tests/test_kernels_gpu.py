@@ -194,6 +194,34 @@ def test_skinny_linear_matches_fp32(m, n, k, bias, variant):
     assert err < 1e-2, err
 
 
+@pytest.mark.parametrize("m", [1, 7, 16, 17, 40, 48, 64])
+@pytest.mark.parametrize("n,k,bias,pair", [(6144, 4096, False, False), (4096, 14336, False, False),
+                                           (1536, 1024, True, False), (128, 256, True, False),
+                                           (2 * 14336, 4096, False, True), (2 * 64, 512, False, True),
+                                           (128256, 4096, False, False)])
+@pytest.mark.parametrize("variant", [0, 4])
+def test_stream_gemm_matches_fp32(m, n, k, bias, pair, variant):
+    """LDS-staged streaming projection (split reduction + fixed-order combine) against fp32."""
+    torch.manual_seed(m * 7 + n)
+    x = torch.randn(m, k, device=DEV).to(BF)
+    w = (torch.randn(n, k, device=DEV) * 0.03).to(BF)
+    b = torch.randn(n, device=DEV).to(BF) if bias else None
+    prev = ops.set_gemm_variant(variant)
+    try:
+        got = ops._stream_gemm(x, w, b, pair)
+        again = ops._stream_gemm(x, w, b, pair)
+    finally:
+        ops.set_gemm_variant(prev)
+    assert got is not None, "shape was expected to be tiled by the kernel"
+    want = torch.nn.functional.linear(x.float(), w.float(), None if b is None else b.float())
+    if pair:
+        want = torch.nn.functional.silu(want[:, : n // 2]) * want[:, n // 2:]
+    assert got.shape == want.shape
+    err = (got.float() - want).abs().max().item() / want.abs().max().item()
+    assert err < 1e-2, err
+    assert torch.equal(got, again), "the split reduction must be reproducible"
+
+
 def test_skinny_linear_strided_rows_and_fallback():
     torch.manual_seed(3)
     base = torch.randn(9, 2 * 4096, device=DEV).to(BF)

@@ -255,7 +255,7 @@ class TransformerModel:
 
     def compute_logits(self, hidden: torch.Tensor) -> torch.Tensor:
         """First-stage ranks only (they hold the LM head shards)."""
-        logits = F.linear(hidden, self.lm_head)
+        logits = ops.linear(hidden, self.lm_head)
         if self.tp_size > 1:
             logits = tp_all_gather_last_dim(logits)
         return logits[:, : self.cfg.vocab_size]

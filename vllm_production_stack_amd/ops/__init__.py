@@ -32,7 +32,8 @@ def _kernels():
             "vpsa_kv_scatter_pages", "vpsa_cachegen_encode", "vpsa_cachegen_decode",
             "vpsa_moe_topk_softmax", "vpsa_moe_align", "vpsa_moe_permute", "vpsa_moe_combine",
             "vpsa_moe_gemv", "vpsa_moe_mfma", "vpsa_lora_shrink", "vpsa_lora_expand",
-            "vpsa_skinny_gemm", "vpsa_hbm_read_probe", "vpsa_set_gemm_variant",
+            "vpsa_skinny_gemm", "vpsa_hbm_read_probe", "vpsa_set_gemm_variant", "vpsa_stream_gemm",
+            "vpsa_stream_gemm_splits", "vpsa_set_stream_targets",
         ):
             getattr(lib, name).restype = c_int
         if os.environ.get("VPSA_PREFILL_VARIANT"):  # pin one prefill kernel for A/B runs
@@ -252,28 +253,52 @@ def _skinny(x2, w, bias, pair):
     return out if rc == 0 else None
 
 
+def _stream_gemm(x2, w, bias, pair):
+    """Streaming projection kernel (LDS-staged, reduction split across workgroups)."""
+    lib = _kernels()
+    m, n, k = x2.shape[0], w.shape[0], w.shape[1]
+    splits = int(lib.vpsa_stream_gemm_splits(c_int(m), c_int(n), c_int(k), c_int(1 if pair else 0)))
+    if splits <= 0:
+        return None
+    out = torch.empty((m, n // 2 if pair else n), dtype=x2.dtype, device=x2.device)
+    ws = torch.empty((splits * m * n,), dtype=torch.float32, device=x2.device) if splits > 1 else None
+    rc = lib.vpsa_stream_gemm(_p(x2), c_long(x2.stride(0)), _p(w), _p(bias), _p(out), c_long(out.stride(0)),
+                              _p(ws), c_int(m), c_int(n), c_int(k), c_int(1 if pair else 0),
+                              c_int(splits), _stream())
+    return out if rc == 0 else None
+
+
 def _skinny_ok(x, w, bias):
     return (_skinny_enabled and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
             and w.is_contiguous() and x.dim() == 2 and 0 < x.shape[0] <= SKINNY_MAX_ROWS
             and x.stride(1) == 1 and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous())))
 
 
-# Measured on MI355X (profiles/gemm_micro_graph.jsonl, HIP-graph replay, Llama-3-8B shapes): the
-# kernel beats the library GEMM for square-ish projections (o-proj: 9.7 vs 14.9 us at 1-8 rows,
-# 11.3 vs 15.0 at 16) and for the fused SwiGLU up-projection up to 8 rows (55.7-58.2 us vs
-# 60.3-61.4 for GEMM + activation); from ~24 rows on the library wins everywhere.
-SKINNY_PLAIN_MAX_ROWS = 16
-SKINNY_PLAIN_MAX_WEIGHT_ELEMS = 4096 * 4096 + 1
-SKINNY_PAIR_MAX_ROWS = 8
+# Dispatch thresholds measured on MI355X (profiles/gemm_micro_graph.jsonl, HIP-graph replay,
+# Llama-3-8B shapes, microseconds: library / register-direct / streaming kernel):
+#   o-proj  4096x4096   1-16 rows: 14.9-15.0 /  9.6-11.4 / 11.1-14.4   -> register-direct
+#   qkv     6144x4096   1-16 rows: 14.2      / 14.0-19.2 / 12.8-14.0   -> streaming
+#   gate_up 28672x4096  1-16 rows: 60.8-61.9 (+ activation) / 55.7-63 / 41.3-45.2; 24-32 rows:
+#                                  55 / - / 48.5-49.3                    -> streaming up to 32 rows
+#   lm_head 128256x4096 1-16 rows: 187-189   / 209-288   / 173-184     -> streaming
+#   down    4096x14336: the library wins at every batch (24.8 vs 25.6)  -> library
+# From ~24 rows on (40 rows: qkv 17 vs 20, gate_up 53 vs 52) the library GEMM is as good or better.
+SMALL_BATCH_ROWS = 16
+PAIR_STREAM_MAX_ROWS = 32
+DIRECT_MAX_WEIGHT_ELEMS = 4096 * 4096
+STREAM_MAX_K = 8192
 
 
 def linear(x, w, bias=None):
-    """y = x @ w.T (+ bias).  Small decode batches against a square-ish weight run the
-    weight-streaming MFMA kernel of ``csrc/kernels/gemm.hip``; everything else goes to the
-    library GEMM (hipBLASLt)."""
-    if (x.dim() == 2 and x.shape[0] <= SKINNY_PLAIN_MAX_ROWS and w.numel() < SKINNY_PLAIN_MAX_WEIGHT_ELEMS
-            and _skinny_ok(x, w, bias)):
-        y = _skinny(x, w, bias, False)
+    """y = x @ w.T (+ bias).  Decode batches of up to 16 rows run the weight-streaming MFMA
+    kernels of ``csrc/kernels/gemm.hip`` (which one depends on the weight's shape); everything
+    else goes to the library GEMM (hipBLASLt)."""
+    if x.dim() == 2 and x.shape[0] <= SMALL_BATCH_ROWS and _skinny_ok(x, w, bias):
+        y = None
+        if w.numel() <= DIRECT_MAX_WEIGHT_ELEMS:
+            y = _skinny(x, w, bias, False)
+        elif w.shape[1] <= STREAM_MAX_K:
+            y = _stream_gemm(x, w, bias, False)
         if y is not None:
             return y
     return torch.nn.functional.linear(x, w, bias)
@@ -282,8 +307,10 @@ def linear(x, w, bias=None):
 def gate_up_silu(x, w_gate_up):
     """silu(x @ Wg.T) * (x @ Wu.T) for ``w_gate_up = [Wg; Wu]``: fused in one kernel for
     decode batches, library GEMM + activation kernel otherwise."""
-    if x.dim() == 2 and x.shape[0] <= SKINNY_PAIR_MAX_ROWS and _skinny_ok(x, w_gate_up, None):
-        y = _skinny(x, w_gate_up, None, True)
+    if x.dim() == 2 and x.shape[0] <= PAIR_STREAM_MAX_ROWS and _skinny_ok(x, w_gate_up, None):
+        y = _stream_gemm(x, w_gate_up, None, True)
+        if y is None and x.shape[0] <= 8:
+            y = _skinny(x, w_gate_up, None, True)
         if y is not None:
             return y
     return silu_and_mul(torch.nn.functional.linear(x, w_gate_up))
