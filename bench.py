@@ -37,6 +37,19 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _default_base_port() -> int:
+    """Router on base, engine of rank r on base + 1 + r.  Derived from the rendezvous port when
+    there is one, so that back-to-back launches with different rendezvous ports never meet a
+    listener of the previous run that is still shutting down."""
+    if os.environ.get("VPSA_BENCH_PORT"):
+        return int(os.environ["VPSA_BENCH_PORT"])
+    try:
+        mp = int(os.environ.get("MASTER_PORT", "0"))
+    except ValueError:
+        mp = 0
+    return 18100 + (mp % 500) * 20 if mp else 18100
+
+
 def parse() -> argparse.Namespace:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,7 +69,7 @@ def parse() -> argparse.Namespace:
                     help="cap the HBM KV pool (pages of 64 tokens) to exercise the host tier; 0 = size from HBM")
     ap.add_argument("--prefill-step-ms", type=float, default=30.0,
                     help="engine's latency-aware prefill admission target (0 = token budget only)")
-    ap.add_argument("--base-port", type=int, default=int(os.environ.get("VPSA_BENCH_PORT", "18100")))
+    ap.add_argument("--base-port", type=int, default=_default_base_port())
     ap.add_argument("--clients", type=int, default=0, help="load-generator processes (0 = auto)")
     ap.add_argument("--device", default="cuda", help="cpu runs a plumbing rehearsal (tiny models)")
     # internal: load-generator mode
