@@ -106,7 +106,7 @@ def decode_case(n_seqs: int, ctx: int, iters: int) -> dict:
             ops.paged_decode(q, out, pool, 0, bt, ctxs, N_Q, N_KV, HD, scale, splits, ws_o, ws_ml)
 
         entry = {}
-        for dv in (0, 1):
+        for dv in (0, 1, 2):
             ops.set_decode_variant(dv)
             ms = timed(run, iters)
             entry[f"v{dv}"] = {"ms": round(ms, 4), "tb_per_s": round(kv_bytes / ms / 1e9, 3)}

@@ -527,7 +527,11 @@ VPSA_EXPORT int vpsa_paged_prefill(const void* q, long q_stride, void* out, long
 // grid = (num_seqs, n_kv, num_splits); block = 256 (4 waves, interleaved over 32-key chunks).
 // Requires G = n_q / n_kv <= 16.
 // ---------------------------------------------------------------------------------
-template <bool PIPE>
+// MODE 0: one register set per wave; 1: software-pipelined over two chunks four apart; 2: a
+// wave takes both 32-key halves of a page together, so the two halves of every 128-byte V line
+// (64 keys of one channel) are requested back to back by the same wave instead of by two waves
+// that may have drifted apart by more than the caches hold.
+template <int MODE>
 __global__ __launch_bounds__(256) void paged_decode_kernel(
     const uint16_t* __restrict__ q, long q_stride, uint16_t* __restrict__ out, long out_stride,
     const uint16_t* __restrict__ cache, long page_stride, long v_offset,
@@ -552,7 +556,8 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
   const int ctx = ctx_lens[seq];
 
   const int nchunks = (ctx + 31) >> 5;
-  const int per_split = (nchunks + num_splits - 1) / num_splits;
+  int per_split = (nchunks + num_splits - 1) / num_splits;
+  if (MODE == 2) per_split = (per_split + 1) & ~1;  // splits begin on page boundaries
   const int c_begin = split * per_split;
   int c_end = c_begin + per_split;
   if (c_end > nchunks) c_end = nchunks;
@@ -646,7 +651,16 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
     }
   };
 
-  if (PIPE) {
+  if (MODE == 2) {
+    u32x4 kfa[2][4], vfa[8], kfb[2][4], vfb[8];
+    for (int c = c_begin + 2 * wave; c < c_end; c += 8) {
+      const bool two = c + 1 < c_end;
+      load_chunk(c, kfa, vfa);
+      if (two) load_chunk(c + 1, kfb, vfb);
+      compute_chunk(c, kfa, vfa);
+      if (two) compute_chunk(c + 1, kfb, vfb);
+    }
+  } else if (MODE == 1) {
     // two register sets: the loads of the wave's next chunk are in flight while the current
     // one is multiplied (the wave count per SIMD drops, each wave keeps twice the bytes in flight)
     u32x4 kfa[2][4], vfa[8], kfb[2][4], vfb[8];
@@ -739,7 +753,7 @@ __global__ __launch_bounds__(128) void decode_reduce_kernel(const float* __restr
   out[(long)seq * out_stride + head * HEAD_DIM + d] = __builtin_bit_cast(uint16_t, b);
 }
 
-// 0 = one register set per wave, 1 = software-pipelined (two register sets)
+// 0 = one register set per wave, 1 = software-pipelined (two register sets), 2 = page-paired
 static int g_decode_variant = 0;
 VPSA_EXPORT int vpsa_set_decode_variant(int v) {
   const int old = g_decode_variant;
@@ -756,14 +770,20 @@ VPSA_EXPORT int vpsa_paged_decode(const void* q, long q_stride, void* out, long 
   if (n_q % n_kv != 0 || n_q / n_kv > 16 || num_splits < 1) return -1;
   if (num_splits > 1 && (!ws_o || !ws_ml)) return -1;
   dim3 grid(num_seqs, n_kv, num_splits), block(256);
-  if (g_decode_variant == 1) {
-    hipLaunchKernelGGL(paged_decode_kernel<true>, grid, block, 32768 + 512, stream,
+  if (g_decode_variant == 2) {
+    hipLaunchKernelGGL(paged_decode_kernel<2>, grid, block, 32768 + 512, stream,
+                       (const uint16_t*)q, q_stride, (uint16_t*)out, out_stride,
+                       (const uint16_t*)cache, page_stride, v_offset, block_tables, max_blocks,
+                       ctx_lens, (float*)ws_o, (float*)ws_ml, n_q, n_kv, num_splits,
+                       scale * 1.4426950408889634f);
+  } else if (g_decode_variant == 1) {
+    hipLaunchKernelGGL(paged_decode_kernel<1>, grid, block, 32768 + 512, stream,
                        (const uint16_t*)q, q_stride, (uint16_t*)out, out_stride,
                        (const uint16_t*)cache, page_stride, v_offset, block_tables, max_blocks,
                        ctx_lens, (float*)ws_o, (float*)ws_ml, n_q, n_kv, num_splits,
                        scale * 1.4426950408889634f);
   } else
-  hipLaunchKernelGGL(paged_decode_kernel<false>, grid, block, 32768 + 512, stream, (const uint16_t*)q,
+  hipLaunchKernelGGL(paged_decode_kernel<0>, grid, block, 32768 + 512, stream, (const uint16_t*)q,
                      q_stride, (uint16_t*)out, out_stride, (const uint16_t*)cache, page_stride,
                      v_offset, block_tables, max_blocks, ctx_lens, (float*)ws_o, (float*)ws_ml,
                      n_q, n_kv, num_splits, scale * 1.4426950408889634f);

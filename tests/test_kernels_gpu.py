@@ -144,7 +144,7 @@ def test_paged_prefill_forced_rescale():
 
 @pytest.mark.parametrize("n_q,n_kv", [(32, 8), (8, 8), (64, 8)])
 @pytest.mark.parametrize("splits", [1, 3, 8])
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_paged_decode_matches_reference(n_q, n_kv, splits, variant):
     torch.manual_seed(10)
     hd, layers = 128, 2

@@ -55,7 +55,8 @@ def set_prefill_variant(v: int) -> int:
 
 def set_decode_variant(v: int) -> int:
     """Select the decode attention kernel (0: one register set per wave, 1: software-pipelined
-    with two register sets).  Returns the previous selection."""
+    with two register sets, 2: a wave takes both halves of a page).  Returns the previous
+    selection."""
     return int(_kernels().vpsa_set_decode_variant(c_int(v)))
 
 
