@@ -301,6 +301,50 @@ def test_cachegen_codec():
     assert rel < 0.03, rel
 
 
+@pytest.mark.parametrize("n_ctx,spc,per_stream", [(4, 256, 64), (32, 512, 256), (2, 512, 1000)])
+def test_rans_gpu_matches_numpy_definition_bit_for_bit(n_ctx, spc, per_stream):
+    import numpy as np
+
+    g = torch.Generator().manual_seed(n_ctx * 1000 + spc)
+    ctx_len = spc * per_stream
+    sym = torch.clamp(torch.round(torch.randn(n_ctx * ctx_len, generator=g) * 7), -128, 127).to(torch.int8)
+    sym[ctx_len:2 * ctx_len] = 11                                              # single-symbol context
+    sym[:ctx_len // 2] = torch.randint(-128, 128, (ctx_len // 2,), generator=g, dtype=torch.int8)  # flat half
+    f_ref, st_ref, sz_ref, co_ref = ref.rans_encode(sym.numpy(), n_ctx, spc)
+    freq, states, sizes, coded = ops.rans_encode(sym.to(DEV), n_ctx, spc)
+    assert np.array_equal(freq.cpu().numpy().view(np.uint16).reshape(n_ctx, 256), f_ref)
+    assert np.array_equal(sizes.cpu().numpy().view(np.uint16), sz_ref)
+    assert np.array_equal(states.cpu().numpy().view(np.uint32), st_ref)
+    assert np.array_equal(coded.cpu().numpy(), co_ref)
+    back = ops.rans_decode(freq, states, sizes, coded, sym.numel(), n_ctx, spc)
+    assert torch.equal(back.cpu(), sym)
+    # damaged input: wrong bytes decode to garbage of the right shape, never out of bounds
+    junk = ops.rans_decode(freq, states, sizes, coded[: coded.numel() // 2].contiguous(), sym.numel(), n_ctx, spc)
+    assert junk.shape == sym.shape
+
+
+def test_cachegen_page_on_gpu_uses_the_rans_stage_and_matches_the_host_coder(monkeypatch):
+    from vllm_production_stack_amd.kv.serde import SERDE_CACHEGEN_RANS, PageSerde, _HDR
+
+    n_layers, n_kv, hd = 32, 8, 128
+    torch.manual_seed(9)
+    page = (torch.randn(n_layers * 2 * n_kv * 64 * hd, device=DEV) * 0.7).to(BF)
+    cg = PageSerde(n_layers, n_kv, hd, BF, "cachegen")
+    blob = cg.encode(page)
+    assert _HDR.unpack_from(blob, 0)[2] == SERDE_CACHEGEN_RANS
+    back = cg.decode(blob, torch.device(DEV))
+    monkeypatch.setenv("VPSA_CACHEGEN_HOST_CODER", "1")
+    blob_host = cg.encode(page)
+    assert _HDR.unpack_from(blob_host, 0)[2] == 1
+    assert torch.equal(cg.decode(blob_host, torch.device(DEV)), back)      # same quantiser, lossless stages
+    assert len(blob) < 1.08 * len(blob_host)                               # static tables cost a few per cent
+    assert len(blob) < 0.5 * page.numel() * 2
+    monkeypatch.delenv("VPSA_CACHEGEN_HOST_CODER")
+    # a CPU host reads it too (its dequantiser is the PyTorch definition: equal up to rounding)
+    on_cpu = cg.decode(blob, torch.device("cpu")).to(DEV).float()
+    assert (on_cpu - back.float()).abs().max().item() <= 0.02 * back.float().abs().max().item()
+
+
 def test_moe_routing():
     torch.manual_seed(17)
     t, e, k, hidden = 300, 8, 2, 4096

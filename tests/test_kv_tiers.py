@@ -56,6 +56,47 @@ def test_page_serde_naive_and_cachegen():
     assert (x - back).abs().mean() / x.abs().mean() < 0.15
 
 
+def test_rans_reference_roundtrip_and_gain():
+    """NumPy definition of the GPU entropy stage: exact round trip on Gaussian, constant and
+    uniform contexts, output close to the zeroth-order entropy."""
+    from vllm_production_stack_amd.ops import reference as ref
+
+    rng = np.random.default_rng(1)
+    n_ctx, spc, ctx_len = 4, 256, 256 * 128
+    sym = np.clip(np.round(rng.normal(0, 5, n_ctx * ctx_len)), -128, 127).astype(np.int8)
+    sym[ctx_len:2 * ctx_len] = -3                                        # one symbol only
+    sym[2 * ctx_len:3 * ctx_len] = rng.integers(-128, 128, ctx_len)      # incompressible
+    freq, states, sizes, coded = ref.rans_encode(sym, n_ctx, spc)
+    assert freq.shape == (n_ctx, 256) and (freq.astype(int).sum(1) == 4096).all()
+    assert sizes.astype(int).sum() == coded.size and sizes.max() <= 2 * ctx_len // spc
+    back = ref.rans_decode(freq, states, sizes, coded, sym.size, n_ctx, spc)
+    assert np.array_equal(back.view(np.int8), sym)
+    first = sym[:ctx_len].view(np.uint8)
+    p = np.bincount(first, minlength=256) / ctx_len
+    entropy_bytes = -(p[p > 0] * np.log2(p[p > 0])).sum() * ctx_len / 8
+    assert sizes[:spc].astype(int).sum() < 1.03 * entropy_bytes
+    assert sizes[spc:2 * spc].astype(int).sum() == 0                     # a constant context costs nothing
+
+
+def test_cachegen_rans_payload_restores_like_the_range_coder():
+    """Serde kind 2 (quantiser + rANS) read back on a CPU-only host equals kind 1 of the same page."""
+    n_layers, n_kv, hd = 3, 1, 128
+    torch.manual_seed(5)
+    page = torch.randn(n_layers * 2 * n_kv * 64 * hd).to(torch.bfloat16)
+    cg = PageSerde(n_layers, n_kv, hd, torch.bfloat16, "cachegen", levels=[127, 31, 15])
+    via_range_coder = cg.decode(cg.encode(page), torch.device("cpu"))
+    lv = torch.tensor(cg.levels, dtype=torch.int32)
+    from vllm_production_stack_amd import ops
+    sym, scales = ops.cachegen_encode(page, lv, cg.unit_elems, n_layers)
+    blob = cg.pack(cg.rans_payload(sym, scales), None)
+    assert cg.unpack(blob)[0] == "rans"
+    assert torch.equal(cg.decode(blob, torch.device("cpu")), via_range_coder)
+    assert torch.equal(cg.restore(cg.unpack(blob), torch.device("cpu")), via_range_coder)
+    assert len(blob) < 0.6 * page.numel() * 2
+    with pytest.raises(ValueError):
+        cg.decode(blob[:-100], torch.device("cpu"))
+
+
 def test_host_offload_survives_hbm_eviction():
     eng = engine(pages=12, local_cpu=True, max_local_cpu_gb=0.05)
     a, b, c = prompts(3, 330)

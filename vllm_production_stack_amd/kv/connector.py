@@ -282,7 +282,7 @@ class KVConnector:
                 t = torch.from_numpy(got[1]).view(self.pool.dtype)
                 self.pool[p].view(-1).copy_(t.to(self.device))
             else:
-                self.pool[p].view(-1).copy_(self.serde.dequantize(got[1], got[2], self.device).view(-1))
+                self.pool[p].view(-1).copy_(self.serde.restore(got, self.device).view(-1))
         return left
 
     def _upload_staged(self, todo: list[tuple[int, int]]) -> None:

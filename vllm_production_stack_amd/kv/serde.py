@@ -3,17 +3,24 @@
 ``naive``    header + raw page bytes (what every reference example configures:
              /root/reference/tutorials/assets/values-06-shared-storage.yaml:53).
 ``cachegen`` lossy: anchor-delta + layer-dependent quantisation on the GPU
-             (``cachegen_encode`` kernel), then an adaptive range coder on the host
-             (``libvpsa_kvio``).  Typically 3-4x smaller than bf16.
+             (``cachegen_encode`` kernel), then an entropy stage.  On a GPU that stage is the
+             interleaved rANS coder of ``csrc/kernels/rans.hip`` (serde kind 2: the page is
+             quantised, coded and packed on the device, the compressed bytes are what crosses
+             PCIe; decoding mirrors it).  On a CPU-only host it is the adaptive range coder of
+             ``libvpsa_kvio`` (kind 1, ~30 M symbols/s).  Both are 2-4x smaller than bf16; either
+             side reads both kinds.
 
 Wire format: 32-byte header ``VPKV | version u16 | serde u16 | n_layers u32 | n_kv u32 |
 head_dim u32 | page_tokens u32 | payload_len u64`` followed by the payload.  For cachegen
-the payload is ``scales fp32[n_groups] | rc_len u64 | range-coded symbols``.
+the payload is ``scales fp32[n_groups] | rc_len u64 | range-coded symbols`` (kind 1) or
+``spc u32 | streams u32 | coded_len u64 | scales fp32[n_groups] | freq u16[n_layers * 256] |
+states u32[streams] | sizes u16[streams] | coded bytes`` (kind 2).
 """
 
 from __future__ import annotations
 
 import ctypes
+import os
 import struct
 
 import numpy as np
@@ -23,6 +30,10 @@ from .. import _native, ops
 
 MAGIC = b"VPKV"
 SERDE_NAIVE, SERDE_CACHEGEN = 0, 1
+# quantiser + GPU rANS entropy stage (what a GPU engine writes for "cachegen"); kind 1, the
+# host range coder, remains for CPU hosts and for blobs already stored
+SERDE_CACHEGEN_RANS = 2
+_RANS_HDR = struct.Struct("<IIQ")  # streams per context, streams, coded bytes
 _HDR = struct.Struct("<4sHHIIIIQ")
 
 _kvio = None
@@ -91,18 +102,38 @@ class PageSerde:
         sym_np, sc_np = self.quantize(flat)
         return self.pack(sym_np, sc_np)
 
-    def quantize(self, flat: torch.Tensor) -> tuple[np.ndarray, np.ndarray]:
-        """GPU half of the cachegen encoder: anchor/delta quantisation kernel, then the int8
-        symbols and fp32 scales come to the host."""
+    def _rans_ok(self, device) -> bool:
+        return (torch.device(device).type == "cuda" and (2 * self.unit_elems) % ops.RANS_SPC == 0
+                and os.environ.get("VPSA_CACHEGEN_HOST_CODER", "0") != "1")
+
+    def quantize(self, flat: torch.Tensor):
+        """GPU half of the cachegen encoder.  On a GPU: anchor/delta quantisation kernel and the
+        rANS entropy stage, one device-to-host copy of the finished payload -> (payload, None).
+        Otherwise the int8 symbols and fp32 scales come back for the host range coder
+        -> (symbols, scales)."""
         lv = self._levels_dev.get(flat.device)
         if lv is None:
             lv = torch.tensor(self.levels, dtype=torch.int32, device=flat.device)
             self._levels_dev[flat.device] = lv
         sym, scales = ops.cachegen_encode(flat.contiguous(), lv, self.unit_elems, self.n_layers)
+        if self._rans_ok(flat.device):
+            return self.rans_payload(sym, scales), None
         return sym.cpu().numpy(), scales.float().cpu().numpy()
 
-    def pack(self, sym_np: np.ndarray, sc_np: np.ndarray) -> bytes:
-        """Host half: range-code the symbols (releases the GIL: safe to run on worker threads)."""
+    def rans_payload(self, sym: torch.Tensor, scales: torch.Tensor) -> np.ndarray:
+        """Entropy-code quantised symbols where they are and return the kind-2 payload bytes."""
+        freq, states, sizes, coded = ops.rans_encode(sym.view(-1), self.n_layers)
+        body = torch.cat([scales.float().contiguous().view(-1).view(torch.uint8),
+                          freq.view(torch.uint8), states.view(torch.uint8), sizes.view(torch.uint8), coded])
+        head = _RANS_HDR.pack(ops.RANS_SPC, states.numel(), coded.numel())
+        return np.concatenate([np.frombuffer(head, dtype=np.uint8), body.cpu().numpy()])
+
+    def pack(self, sym_np: np.ndarray, sc_np: np.ndarray | None) -> bytes:
+        """Host half: frame a finished rANS payload, or range-code the symbols (releases the
+        GIL: safe to run on worker threads)."""
+        if sc_np is None:
+            return _HDR.pack(MAGIC, 1, SERDE_CACHEGEN_RANS, self.n_layers, self.n_kv, self.head_dim,
+                             ops.PAGE, sym_np.size) + sym_np.tobytes()
         coded = rc_encode(sym_np, 2 * self.unit_elems, self.n_layers)
         payload = sc_np.tobytes() + struct.pack("<Q", len(coded)) + coded
         return self._header(len(payload)) + payload
@@ -122,8 +153,35 @@ class PageSerde:
         if kind == SERDE_NAIVE:
             t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).view(self.dtype)
             return t.to(device)
+        if kind == SERDE_CACHEGEN_RANS:
+            return self.restore_rans(np.frombuffer(payload, dtype=np.uint8), device)
         sym_np, sc_np = self._unpack_payload(payload)
         return self.dequantize(sym_np, sc_np, device)
+
+    def restore_rans(self, payload: np.ndarray, device) -> torch.Tensor:
+        """rANS payload (host bytes) -> KV page on ``device``: one host-to-device copy, entropy
+        decode and dequantisation on the GPU (NumPy definitions on a CPU-only host)."""
+        spc, n_streams, coded_len = _RANS_HDR.unpack_from(payload, 0)
+        n_groups = self.page_elems // 64
+        a = _RANS_HDR.size
+        cuts = np.cumsum([a, 4 * n_groups, 2 * 256 * self.n_layers, 4 * n_streams, 2 * n_streams, coded_len])
+        if n_streams != self.n_layers * spc or cuts[-1] > payload.size:
+            raise ValueError("damaged cachegen payload")
+        body = torch.from_numpy(payload[a:cuts[-1]].copy()).to(device)
+        o = cuts - a
+        scales = body[o[0]:o[1]].view(torch.float32)
+        freq = body[o[1]:o[2]].view(torch.int16)
+        states = body[o[2]:o[3]].view(torch.int32)
+        sizes = body[o[3]:o[4]].view(torch.int16)
+        coded = body[o[4]:o[5]]
+        sym = ops.rans_decode(freq, states, sizes, coded, self.page_elems, self.n_layers, spc)
+        return ops.cachegen_decode(sym, scales, self.unit_elems)
+
+    def restore(self, got: tuple, device) -> torch.Tensor:
+        """Finish what ``unpack`` started (its "codec" and "rans" results)."""
+        if got[0] == "rans":
+            return self.restore_rans(got[1], device)
+        return self.dequantize(got[1], got[2], device)
 
     def _unpack_payload(self, payload) -> tuple[np.ndarray, np.ndarray]:
         n_groups = self.page_elems // 64
@@ -143,6 +201,8 @@ class PageSerde:
         payload = memoryview(blob)[_HDR.size:_HDR.size + plen]
         if kind == SERDE_NAIVE:
             return ("raw", np.frombuffer(payload, dtype=np.uint8).copy())
+        if kind == SERDE_CACHEGEN_RANS:
+            return ("rans", np.frombuffer(payload, dtype=np.uint8))  # entropy decode happens on the GPU
         return ("codec",) + self._unpack_payload(payload)
 
     def dequantize(self, sym_np: np.ndarray, sc_np: np.ndarray, device: torch.device) -> torch.Tensor:

@@ -33,7 +33,8 @@ def _kernels():
             "vpsa_moe_topk_softmax", "vpsa_moe_align", "vpsa_moe_permute", "vpsa_moe_combine",
             "vpsa_moe_gemv", "vpsa_moe_mfma", "vpsa_lora_shrink", "vpsa_lora_expand",
             "vpsa_skinny_gemm", "vpsa_hbm_read_probe", "vpsa_set_gemm_variant", "vpsa_stream_gemm",
-            "vpsa_stream_gemm_splits", "vpsa_set_stream_targets",
+            "vpsa_stream_gemm_splits", "vpsa_set_stream_targets", "vpsa_rans_encode", "vpsa_rans_pack",
+            "vpsa_rans_decode",
         ):
             getattr(lib, name).restype = c_int
         if os.environ.get("VPSA_PREFILL_VARIANT"):  # pin one prefill kernel for A/B runs
@@ -412,6 +413,68 @@ def cachegen_decode(symbols, scales, unit_elems, out=None):
                                          c_long(unit_elems), _stream())
     _check(rc, "cachegen_decode")
     return out
+
+
+# --------------------------------------------------------------------------- rANS entropy stage
+RANS_SPC = 512  # streams per context: 256 symbols per stream for a Llama-3-8B layer (K + V)
+
+
+def rans_encode(sym, n_ctx, spc=RANS_SPC):
+    """Entropy-code int8/uint8 symbols (``n_ctx`` equal contexts) with the interleaved rANS
+    coder.  -> (freq int16 [n_ctx * 256], states int32 [n_ctx * spc], sizes int16 [n_ctx * spc],
+    coded uint8 [sum of sizes]); the 16/32-bit tensors hold unsigned values bit for bit.
+    Synchronises once (the coded length sizes the output)."""
+    if not sym.is_cuda:
+        import numpy as np
+
+        f, st, sz, co = reference.rans_encode(sym.contiguous().view(torch.uint8).numpy(), n_ctx, spc)
+        return (torch.from_numpy(f.view(np.int16).reshape(-1).copy()), torch.from_numpy(st.view(np.int32).copy()),
+                torch.from_numpy(sz.view(np.int16).copy()), torch.from_numpy(co.copy()))
+    sym = sym.contiguous().view(torch.uint8).view(-1)
+    n, dev = sym.numel(), sym.device
+    n_streams = n_ctx * spc
+    if n % n_ctx or (n // n_ctx) % spc:
+        raise ValueError("rans_encode: symbols do not divide into contexts / streams")
+    cap = 2 * (n // n_ctx // spc)
+    hist = torch.zeros(n_ctx * 256, dtype=torch.int32, device=dev)
+    freq = torch.empty(n_ctx * 256, dtype=torch.int16, device=dev)
+    cum = torch.empty(n_ctx * 256, dtype=torch.int16, device=dev)
+    scratch = torch.empty(n_streams * cap, dtype=torch.uint8, device=dev)
+    states = torch.empty(n_streams, dtype=torch.int32, device=dev)
+    sizes = torch.empty(n_streams, dtype=torch.int16, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    lib = _kernels()
+    _check(lib.vpsa_rans_encode(_p(sym), c_long(n), c_int(n_ctx), c_int(spc), _p(hist), _p(freq), _p(cum),
+                                _p(scratch), _p(states), _p(sizes), _p(err), _stream()), "rans_encode")
+    sz64 = sizes.to(torch.int64)
+    ends = torch.cumsum(sz64, 0)
+    offsets = ends - sz64
+    total, bad = torch.stack([ends[-1], err[0].to(torch.int64)]).tolist()  # one synchronisation
+    if bad:
+        raise RuntimeError("rans_encode: frequency table could not be normalised")
+    coded = torch.empty(int(total), dtype=torch.uint8, device=dev)
+    _check(lib.vpsa_rans_pack(_p(scratch), _p(sizes), _p(offsets), _p(coded), c_long(n), c_int(n_ctx),
+                              c_int(spc), _stream()), "rans_pack")
+    return freq, states, sizes, coded
+
+
+def rans_decode(freq, states, sizes, coded, n, n_ctx, spc=RANS_SPC):
+    """Inverse of ``rans_encode`` -> int8 symbols [n] on the device of ``coded``."""
+    if not coded.is_cuda:
+        import numpy as np
+
+        out = reference.rans_decode(freq.numpy().view(np.uint16), states.numpy().view(np.uint32),
+                                    sizes.numpy().view(np.uint16), coded.numpy(), n, n_ctx, spc)
+        return torch.from_numpy(out.view(np.int8).copy())
+    dev = coded.device
+    sz64 = sizes.to(torch.int64)
+    offsets = torch.cumsum(sz64, 0) - sz64
+    cum = torch.empty(n_ctx * 256, dtype=torch.int16, device=dev)
+    sym = torch.empty(n, dtype=torch.int8, device=dev)
+    _check(_kernels().vpsa_rans_decode(_p(coded), c_long(coded.numel()), _p(offsets), _p(states), _p(freq),
+                                       _p(cum), _p(sym), c_long(n), c_int(n_ctx), c_int(spc), _stream()),
+           "rans_decode")
+    return sym
 
 
 # --------------------------------------------------------------------------- MoE routing

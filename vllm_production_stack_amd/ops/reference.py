@@ -217,3 +217,99 @@ def lora_expand(h, h_off, b, slots, y, y_off):
         delta = h[rows, h_off:h_off + r_pad].float() @ b[s].float().t()
         y[rows, y_off:y_off + out_dim] = (y[rows, y_off:y_off + out_dim].float() + delta).to(y.dtype)
     return y
+
+
+# --------------------------------------------------------------------------- rANS entropy stage
+# NumPy definition of the interleaved rANS coder of csrc/kernels/rans.hip (same tables, same
+# stream layout, same bytes): the oracle of the GPU kernels and the codec of CPU-only hosts.
+RANS_BITS = 12
+RANS_M = 1 << RANS_BITS
+RANS_LOW = 1 << 23
+
+
+def rans_tables(sym, n_ctx: int):
+    """-> (freq [n_ctx, 256] uint16 summing to 4096 per row, cum [n_ctx, 256] uint32)."""
+    import numpy as np
+
+    sym = np.asarray(sym).view(np.uint8).reshape(n_ctx, -1)
+    total = sym.shape[1]
+    freq = np.zeros((n_ctx, 256), dtype=np.int64)
+    for c in range(n_ctx):
+        cnt = np.bincount(sym[c], minlength=256).astype(np.int64)
+        f = np.where(cnt > 0, np.maximum(1, (cnt * RANS_M + total // 2) // total), 0)
+        i = int(np.argmax(f))  # first index among equals
+        f[i] += RANS_M - int(f.sum())
+        if f[i] < 1:
+            raise ValueError("frequency table cannot be normalised")
+        freq[c] = f
+    cum = np.cumsum(freq, axis=1) - freq
+    return freq.astype(np.uint16), cum.astype(np.uint32)
+
+
+def rans_encode(sym, n_ctx: int, spc: int):
+    """-> (freq uint16 [n_ctx, 256], states uint32 [n_ctx * spc], sizes uint16, coded uint8)."""
+    import numpy as np
+
+    sym = np.asarray(sym).view(np.uint8).reshape(n_ctx, -1)
+    ctx_len = sym.shape[1]
+    length = ctx_len // spc
+    cap = 2 * length
+    freq, cum = rans_tables(sym, n_ctx)
+    n_streams = n_ctx * spc
+    buf = np.zeros((n_streams, cap), dtype=np.uint8)
+    pos = np.full(n_streams, cap, dtype=np.int64)
+    x = np.full(n_streams, RANS_LOW, dtype=np.uint64)
+    ctx_of = np.repeat(np.arange(n_ctx), spc)
+    rows = np.arange(n_streams)
+    per = sym.reshape(n_ctx, length, spc)  # [ctx, k, j]
+    for k in range(length - 1, -1, -1):
+        s = per[:, k, :].reshape(-1)
+        f = freq[ctx_of, s].astype(np.uint64)
+        c = cum[ctx_of, s].astype(np.uint64)
+        x_max = np.uint64((RANS_LOW >> RANS_BITS) << 8) * f
+        while True:
+            m = x >= x_max
+            if not m.any():
+                break
+            pos[m] -= 1
+            buf[rows[m], pos[m]] = (x[m] & np.uint64(0xFF)).astype(np.uint8)
+            x[m] >>= np.uint64(8)
+        x = ((x // f) << np.uint64(RANS_BITS)) + (x % f) + c
+    sizes = (cap - pos).astype(np.uint16)
+    coded = np.concatenate([buf[i, pos[i]:] for i in range(n_streams)]) if n_streams else np.zeros(0, np.uint8)
+    return freq, x.astype(np.uint32), sizes, coded
+
+
+def rans_decode(freq, states, sizes, coded, n: int, n_ctx: int, spc: int):
+    """-> uint8 symbols [n]."""
+    import numpy as np
+
+    freq = np.asarray(freq, dtype=np.uint16).reshape(n_ctx, 256)
+    cum = (np.cumsum(freq.astype(np.int64), axis=1) - freq).astype(np.int64)
+    ctx_len = n // n_ctx
+    length = ctx_len // spc
+    n_streams = n_ctx * spc
+    slot2sym = np.zeros((n_ctx, RANS_M), dtype=np.uint8)
+    for c in range(n_ctx):
+        slot2sym[c] = np.repeat(np.arange(256, dtype=np.uint8), freq[c].astype(np.int64))[:RANS_M]
+    ctx_of = np.repeat(np.arange(n_ctx), spc)
+    sizes64 = np.asarray(sizes).astype(np.int64)
+    rp = np.cumsum(sizes64) - sizes64
+    x = np.asarray(states).astype(np.uint64).copy()
+    coded = np.concatenate([np.asarray(coded, dtype=np.uint8), np.zeros(8, np.uint8)])
+    limit = coded.size - 8
+    out = np.zeros((n_ctx, length, spc), dtype=np.uint8)
+    f64 = freq.astype(np.uint64)
+    for k in range(length):
+        slot = (x & np.uint64(RANS_M - 1)).astype(np.int64)
+        s = slot2sym[ctx_of, slot]
+        out[:, k, :] = s.reshape(n_ctx, spc)
+        x = f64[ctx_of, s] * (x >> np.uint64(RANS_BITS)) + slot.astype(np.uint64) - cum[ctx_of, s].astype(np.uint64)
+        while True:
+            m = x < np.uint64(RANS_LOW)
+            if not m.any():
+                break
+            b = np.where(rp[m] < limit, coded[np.minimum(rp[m], limit)], 0).astype(np.uint64)
+            x[m] = (x[m] << np.uint64(8)) | b
+            rp[m] += 1
+    return out.reshape(-1)
