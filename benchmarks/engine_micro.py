@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--no-chunked", action="store_true")
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--max-num-seqs", type=int, default=64)
+    ap.add_argument("--temperature", type=float, default=0.0, help="> 0: stochastic sampling for every request")
+    ap.add_argument("--top-p", type=float, default=1.0)
+    ap.add_argument("--top-k", type=int, default=-1)
     args = ap.parse_args()
 
     cfg = EngineConfig(model=args.model, max_model_len=32000, max_num_seqs=args.max_num_seqs,
@@ -52,8 +55,8 @@ def main():
         # early requests decode while later ones are still prefilled: give every request enough
         # tokens to be alive through the whole prefill phase and the timed steps
         prefill_steps = (b * args.ctx + args.chunk - 1) // args.chunk + b
-        sp = SamplingParams(max_tokens=args.decode_steps + 4 + prefill_steps, temperature=0,
-                            ignore_eos=True)
+        sp = SamplingParams(max_tokens=args.decode_steps + 4 + prefill_steps, temperature=args.temperature,
+                            top_p=args.top_p, top_k=args.top_k, ignore_eos=True)
         reqs = [eng.add_request(prompt(args.ctx), SamplingParams(**sp.__dict__)) for _ in range(b)]
         torch.cuda.synchronize()
         t0 = time.time()

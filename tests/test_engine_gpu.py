@@ -225,3 +225,22 @@ def test_gpu_engine_tracks_hugging_face_llama(tmp_path):
         # the token the bf16 engine picks is (within bf16 noise) the fp32 model's best token
         spread = (logits.max() - logits.median()).item()
         assert (logits.max() - logits[out[0]]).item() < 0.03 * spread + 0.05, (n, out, spread)
+
+
+def test_sampled_requests_use_the_batched_kernel_and_seeds_reproduce():
+    """Temperature / top-p / top-k requests in one batch with greedy ones: seeded requests give
+    the same tokens whatever shares the batch, unseeded ones differ between runs."""
+    eng = gpu_engine("tiny-llama-gqa")
+    g = torch.Generator().manual_seed(3)
+    prompts = [torch.randint(16, 500, (n,), generator=g).tolist() for n in (40, 70, 25, 33)]
+    seeded = SamplingParams(max_tokens=12, temperature=0.9, top_p=0.9, top_k=50, seed=1234, ignore_eos=True)
+    free = SamplingParams(max_tokens=12, temperature=1.0, ignore_eos=True)
+    greedy = SamplingParams(max_tokens=12, temperature=0.0, ignore_eos=True)
+    alone = eng.generate([prompts[0]], copy.deepcopy(seeded))[0]
+    outs = eng.generate(prompts, [copy.deepcopy(seeded), copy.deepcopy(free), copy.deepcopy(greedy),
+                                  copy.deepcopy(free)])
+    assert outs[0] == alone, "a seeded request does not depend on its batch mates"
+    assert outs[2] == eng.generate([prompts[2]], copy.deepcopy(greedy))[0]
+    again = eng.generate([prompts[1]], copy.deepcopy(free))[0]
+    assert all(len(o) == 12 and all(0 <= t < 1 << 20 for t in o) for o in outs)
+    assert outs[1] != again or outs[3] != again  # unseeded draws move on

@@ -345,6 +345,88 @@ def test_cachegen_page_on_gpu_uses_the_rans_stage_and_matches_the_host_coder(mon
     assert (on_cpu - back.float()).abs().max().item() <= 0.02 * back.float().abs().max().item()
 
 
+def _sampling_reference(row_bf16, temperature, top_p, top_k):
+    """Float64 definition of the kept set: (threshold value, kept mass / largest probability, kept count)."""
+    import numpy as np
+
+    v = row_bf16.float().cpu().numpy().astype(np.float64)
+    p = np.exp((v - v.max()) / max(temperature, 1e-5))
+    thr = -np.inf
+    if 0 < top_k < v.size:
+        thr = np.sort(v)[-top_k]
+    keep = v >= thr
+    z = p[keep].sum()
+    if 0 < top_p < 1:
+        vals = np.unique(v[keep])[::-1]                        # distinct values, descending
+        mass = np.array([p[v == x].sum() for x in vals]) if vals.size < 4096 else None
+        if mass is None:                                       # large rows: group by value with bincount
+            order = np.argsort(-v[keep], kind="stable")
+            sv, sp = v[keep][order], p[keep][order]
+            cuts = np.flatnonzero(np.diff(sv)) + 1
+            mass = np.add.reduceat(sp, np.r_[0, cuts])
+            vals = sv[np.r_[0, cuts]]
+        cum = np.cumsum(mass)
+        j = int(np.searchsorted(cum, top_p * z * (1 - 1e-12)))
+        thr = vals[min(j, vals.size - 1)]
+        keep = v >= thr
+        z = p[keep].sum()
+    return thr, z, int(keep.sum()), p, v
+
+
+@pytest.mark.parametrize("vocab,stride", [(128256, 128256), (1000, 1024), (50, 64)])
+def test_sampling_kernel_keeps_the_right_set(vocab, stride):
+    import numpy as np
+
+    torch.manual_seed(vocab)
+    cases = [(1.0, 1.0, -1), (0.7, 0.9, -1), (1.3, 1.0, 40), (0.8, 0.95, 50), (0.5, 0.3, 5), (1.0, 0.999, 1),
+             (2.0, 0.5, 0)]
+    n = len(cases)
+    buf = torch.zeros(n, stride, device=DEV, dtype=BF)
+    buf[:, :vocab] = (torch.randn(n, vocab, device=DEV) * 2.5).to(BF)
+    logits = buf[:, :vocab]
+    params = torch.tensor([[t, p, float(k)] for t, p, k in cases], dtype=torch.float32, device=DEV)
+    u = torch.rand(n, device=DEV)
+    toks, stats = ops.sample(logits, params, u, want_stats=True)
+    toks2 = ops.sample(logits, params, u)
+    assert torch.equal(toks, toks2), "same inputs, same tokens"
+    stats = stats.cpu().numpy()
+    for i, (t, p, k) in enumerate(cases):
+        thr, z, kept, prob, v = _sampling_reference(logits[i], t, p, k)
+        key = int(stats[i, 0])
+        b = (key & 0x7FFF) if key & 0x8000 else (~key & 0xFFFF)
+        got_thr = np.frombuffer(np.uint32(b << 16).tobytes(), dtype=np.float32)[0]
+        got_thr = -np.inf if key == 0 else got_thr
+        tok = int(toks[i])
+        assert 0 <= tok < vocab and v[tok] >= got_thr, "the drawn token lies in the kept set"
+        if got_thr != thr:
+            # fp32 sums may settle a borderline top-p cut one distinct value away: both sides of
+            # the cut then carry (almost) exactly the target mass
+            lo, hi = min(got_thr, thr), max(got_thr, thr)
+            between = prob[(v >= lo) & (v < hi)].sum()
+            assert between <= 2e-3 * z, (i, got_thr, thr)
+        else:
+            assert int(stats[i, 2]) == kept, (i, stats[i], kept)
+            assert abs(stats[i, 1] - z) <= 2e-3 * z
+
+
+def test_sampling_kernel_draws_from_the_filtered_distribution():
+    import numpy as np
+
+    torch.manual_seed(1)
+    vocab, n = 48, 40000
+    row = (torch.randn(1, 64, device=DEV) * 2).to(BF)
+    logits = row[:, :vocab]
+    for t, p, k in [(1.0, 1.0, -1), (0.8, 0.9, -1), (1.0, 1.0, 5)]:
+        params = torch.tensor([[t, p, float(k)]] * n, dtype=torch.float32, device=DEV)
+        rows = torch.zeros(n, dtype=torch.int32, device=DEV)
+        toks = ops.sample(logits, params, torch.rand(n, device=DEV), rows).cpu().numpy()
+        thr, z, kept, prob, v = _sampling_reference(logits[0], t, p, k)
+        want = np.where(v >= thr, prob, 0.0) / z
+        got = np.bincount(toks, minlength=vocab) / n
+        assert got[want == 0].sum() == 0
+        assert np.abs(got - want).max() < 4 * np.sqrt(want.max() / n) + 2e-3, np.abs(got - want).max()
+
+
 def test_moe_routing():
     torch.manual_seed(17)
     t, e, k, hidden = 300, 8, 2, 4096

@@ -29,7 +29,7 @@ TARGETS = {
     "vpsa_kernels": (
         "hip",
         ["kernels/elementwise.hip", "kernels/attention.hip", "kernels/kvcache.hip", "kernels/moe.hip",
-         "kernels/lora.hip", "kernels/gemm.hip", "kernels/rans.hip"],
+         "kernels/lora.hip", "kernels/gemm.hip", "kernels/rans.hip", "kernels/sampling.hip"],
         [],
     ),
     "vpsa_kvio": ("hip", ["kvio/kvio.cpp"], []),

@@ -196,11 +196,13 @@ class LLMEngine:
         return None
 
     # ------------------------------------------------------------------ convenience
-    def generate(self, prompts: list[list[int]], params: SamplingParams) -> list[list[int]]:
-        """Blocking helper: run the prompts to completion, return generated ids per prompt."""
+    def generate(self, prompts: list[list[int]], params) -> list[list[int]]:
+        """Blocking helper: run the prompts to completion, return generated ids per prompt.
+        ``params``: one ``SamplingParams`` for all prompts or a list with one per prompt."""
         import copy
 
-        reqs = [self.add_request(p, copy.deepcopy(params)) for p in prompts]
+        per = params if isinstance(params, (list, tuple)) else [params] * len(prompts)
+        reqs = [self.add_request(p, copy.deepcopy(sp)) for p, sp in zip(prompts, per)]
         while self.has_work():
             self.step()
         return [r.output_ids for r in reqs]

@@ -1,7 +1,12 @@
-"""Token sampling: greedy rows use the argmax kernel; stochastic rows apply temperature,
-top-k, top-p and (optionally) repetition/presence/frequency penalties in fp32."""
+"""Token sampling.  Greedy rows use the argmax kernel.  On the GPU all stochastic rows of a step
+(temperature / top-k / top-p) are drawn by one launch of the batched sampling kernel
+(``csrc/kernels/sampling.hip``: key-threshold bisection instead of a sort, no host round trip
+per row); rows that ask for penalties or logprobs, and CPU tensors, take the per-row PyTorch
+definitions below."""
 
 from __future__ import annotations
+
+import os
 
 import torch
 
@@ -44,11 +49,17 @@ class Sampler:
             return ids[:n].tolist(), [None] * n
         out: list[int] = []
         infos: list[dict | None] = []
-        greedy_all = (greedy_ids if greedy_ids is not None else ops.argmax(logits[:n]))[:n].tolist()
+        greedy_dev = (greedy_ids if greedy_ids is not None else ops.argmax(logits[:n]))[:n]
+        batched = self._sample_batched(logits, reqs)  # launched before the greedy ids are read back
+        greedy_all = greedy_dev.tolist()
         for i, r in enumerate(reqs):
             p = r.params
             if p.greedy and not self._needs_penalty(p) and p.logprobs is None:
                 out.append(greedy_all[i])
+                infos.append(None)
+                continue
+            if i in batched:
+                out.append(batched[i])
                 infos.append(None)
                 continue
             row = logits[i].float()
@@ -81,6 +92,33 @@ class Sampler:
             else:
                 infos.append(None)
         return out, infos
+
+    def _sample_batched(self, logits: torch.Tensor, reqs: list[Request]) -> dict[int, int]:
+        """Rows that only need temperature / top-k / top-p, drawn in one kernel launch.
+        -> {row index: token}.  The uniform numbers come from the request's own generator when
+        it has a seed (reproducible whatever else is in the batch), else from the engine's."""
+        if not ops.sample_supported(logits) or os.environ.get("VPSA_BATCHED_SAMPLING", "1") == "0":
+            return {}
+        idx = [i for i, r in enumerate(reqs)
+               if not r.params.greedy and not self._needs_penalty(r.params) and r.params.logprobs is None]
+        if not idx:
+            return {}
+        params = torch.tensor([[reqs[i].params.temperature, reqs[i].params.top_p,
+                                float(reqs[i].params.top_k or 0)] for i in idx], dtype=torch.float32)
+        uniform = torch.empty(len(idx), dtype=torch.float32, device=logits.device)
+        unseeded = [j for j, i in enumerate(idx) if reqs[i].params.seed is None]
+        if unseeded:
+            u = torch.rand(len(unseeded), generator=self.gen, device=logits.device)
+            if len(unseeded) == len(idx):
+                uniform = u
+            else:
+                uniform[torch.tensor(unseeded, device=logits.device)] = u
+        for j, i in enumerate(idx):
+            if reqs[i].params.seed is not None:
+                uniform[j:j + 1] = torch.rand(1, generator=self._gen_for(reqs[i]), device=logits.device)
+        rows = torch.tensor(idx, dtype=torch.int32).to(logits.device, non_blocking=True)
+        toks = ops.sample(logits, params.to(logits.device, non_blocking=True), uniform, rows)
+        return dict(zip(idx, toks.tolist()))
 
     @staticmethod
     def _penalize(row: torch.Tensor, r: Request) -> torch.Tensor:

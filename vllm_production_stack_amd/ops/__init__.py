@@ -34,7 +34,7 @@ def _kernels():
             "vpsa_moe_gemv", "vpsa_moe_mfma", "vpsa_lora_shrink", "vpsa_lora_expand",
             "vpsa_skinny_gemm", "vpsa_hbm_read_probe", "vpsa_set_gemm_variant", "vpsa_stream_gemm",
             "vpsa_stream_gemm_splits", "vpsa_set_stream_targets", "vpsa_rans_encode", "vpsa_rans_pack",
-            "vpsa_rans_decode",
+            "vpsa_rans_decode", "vpsa_sample",
         ):
             getattr(lib, name).restype = c_int
         if os.environ.get("VPSA_PREFILL_VARIANT"):  # pin one prefill kernel for A/B runs
@@ -356,6 +356,30 @@ def argmax(logits, out=None):
                                      c_int(logits.shape[1]), c_long(logits.stride(0)), _stream())
     _check(rc, "argmax")
     return out
+
+
+def sample_supported(logits) -> bool:
+    return (logits.is_cuda and logits.dtype == torch.bfloat16 and logits.dim() == 2
+            and logits.stride(1) == 1 and logits.stride(0) % 8 == 0 and logits.data_ptr() % 16 == 0)
+
+
+def sample(logits, params, uniform, rows=None, want_stats=False):
+    """Draw one token per sample from bf16 ``logits`` [*, vocab] in one launch.
+    ``params`` float32 [n, 3] = (temperature, top_p, top_k; top_k <= 0 and top_p >= 1 mean off),
+    ``uniform`` float32 [n] in [0, 1), ``rows`` int32 [n] (logits row of each sample; default
+    sample i reads row i).  -> int64 token ids [n] (and, for tests, [n, 3] = threshold key,
+    kept mass relative to the largest probability, kept count)."""
+    if not sample_supported(logits):
+        raise TypeError("sample: bf16 device logits with 16-byte aligned rows")
+    n = params.shape[0]
+    out = torch.empty((n,), dtype=torch.int64, device=logits.device)
+    stats = torch.empty((n, 3), dtype=torch.float32, device=logits.device) if want_stats else None
+    assert params.dtype == torch.float32 and params.is_contiguous() and uniform.dtype == torch.float32
+    assert rows is None or (rows.dtype == torch.int32 and rows.numel() == n)
+    rc = _kernels().vpsa_sample(_p(logits), c_long(logits.stride(0)), c_int(logits.shape[1]), _p(rows),
+                                _p(params), _p(uniform), _p(out), _p(stats), c_int(n), _stream())
+    _check(rc, "sample")
+    return (out, stats) if want_stats else out
 
 
 # --------------------------------------------------------------------------- KV page movement
