@@ -36,7 +36,7 @@ class RequestState(enum.Enum):
     FINISHED = "finished"
 
 
-@dataclass
+@dataclass(eq=False)  # identity semantics: membership tests must not compare token lists
 class Request:
     request_id: str
     prompt_ids: list[int]

@@ -164,7 +164,7 @@ class Scheduler:
 
         # 1. sequences already running: decode rows first, then unfinished prompt chunks
         for req in sorted(self.running, key=lambda r: r.remaining != 1):
-            if req not in self.running:
+            if out.preempted and any(v is req for v in out.preempted):
                 continue  # preempted by an earlier iteration
             rem = req.remaining
             n = 1 if rem == 1 else min(rem, budget)
