@@ -291,14 +291,27 @@ class ModelRunner:
     def _capture(self, bsz: int, with_lora: bool = False) -> dict:
         dev = self.device
         mp = self.max_pages_per_seq
+        # Graph inputs.  ids/slots and pos/ctx share one device tensor each, and every group has
+        # a pinned host twin that is filled in place and sent with one copy per step (the step
+        # ends with a read-back of the sampled tokens, so a twin is free again before the next
+        # step touches it).  The block-table twin keeps what it holds per row between steps:
+        # a row is rewritten only when another request moves into it or its page list grows.
+        d64 = torch.zeros((2, bsz), dtype=torch.int64, device=dev)
+        d32 = torch.zeros((2, bsz), dtype=torch.int32, device=dev)
+        d64[1].fill_(-1)
+        h64 = torch.zeros((2, bsz), dtype=torch.int64)
+        h32 = torch.zeros((2, bsz), dtype=torch.int32)
+        hbt = torch.zeros((bsz, mp), dtype=torch.int32)
+        if self._pin:
+            h64, h32, hbt = h64.pin_memory(), h32.pin_memory(), hbt.pin_memory()
         st = {
             "lora": torch.full((bsz,), -1, dtype=torch.int32, device=dev),
             "lora_version": self.model.lora.version if with_lora else 0,
-            "ids": torch.zeros(bsz, dtype=torch.int64, device=dev),
-            "pos": torch.zeros(bsz, dtype=torch.int32, device=dev),
-            "slots": torch.full((bsz,), -1, dtype=torch.int64, device=dev),
+            "d64": d64, "d32": d32, "ids": d64[0], "slots": d64[1], "pos": d32[0], "ctx": d32[1],
             "bt": torch.zeros((bsz, mp), dtype=torch.int32, device=dev),
-            "ctx": torch.zeros(bsz, dtype=torch.int32, device=dev),
+            "h64": h64, "h32": h32, "hbt": hbt,
+            "n64": h64.numpy(), "n32": h32.numpy(), "nbt": hbt.numpy(),
+            "row_pages": [None] * bsz, "row_len": [0] * bsz,
         }
         splits = ops.decode_num_splits(bsz, self.n_kv_local, self.max_model_len)
         mc = self.model_cfg
@@ -347,22 +360,35 @@ class ModelRunner:
             self._graphs[key] = st
             log.info("captured decode graph for batch %d%s in %.2fs", bsz,
                      " (LoRA)" if with_lora else "", time.time() - t0)
-        mp = self.max_pages_per_seq
         ids, pos, slots, ctx = [0] * bsz, [0] * bsz, [-1] * bsz, [0] * bsz
-        bt = torch.zeros((bsz, mp), dtype=torch.int32)
+        nbt, row_pages, row_len = st["nbt"], st["row_pages"], st["row_len"]
+        bt_dirty = False
         for i, s in enumerate(decodes):
             r = s.req
             t = s.start
+            pages = r.pages
             ids[i] = r.output_ids[t - r.prompt_len] if t >= r.prompt_len else r.prompt_ids[t]
             pos[i] = t
-            slots[i] = r.pages[t // PAGE] * PAGE + t % PAGE
+            slots[i] = pages[t // PAGE] * PAGE + t % PAGE
             ctx[i] = t + 1
-            bt[i, : len(r.pages)] = torch.tensor(r.pages, dtype=torch.int32)
-        st["ids"].copy_(self._to_dev(ids, torch.int64), non_blocking=True)
-        st["pos"].copy_(self._to_dev(pos, torch.int32), non_blocking=True)
-        st["slots"].copy_(self._to_dev(slots, torch.int64), non_blocking=True)
-        st["ctx"].copy_(self._to_dev(ctx, torch.int32), non_blocking=True)
-        st["bt"].copy_(bt.pin_memory().to(self.device, non_blocking=True), non_blocking=True)
+            k = len(pages)
+            if row_pages[i] is not pages:  # another request (or a re-admitted one) moved in
+                nbt[i, :k] = pages
+                row_pages[i], row_len[i] = pages, k
+                bt_dirty = True
+            elif row_len[i] != k:  # page lists only grow while a request keeps its list
+                lo = min(row_len[i], k)
+                nbt[i, lo:k] = pages[lo:k]
+                row_len[i] = k
+                bt_dirty = True
+        for i in range(n, bsz):  # rows past the batch hold no request (ctx 0: nothing is read)
+            row_pages[i] = None
+        n64, n32 = st["n64"], st["n32"]
+        n64[0], n64[1], n32[0], n32[1] = ids, slots, pos, ctx
+        st["d64"].copy_(st["h64"], non_blocking=True)
+        st["d32"].copy_(st["h32"], non_blocking=True)
+        if bt_dirty:
+            st["bt"].copy_(st["hbt"], non_blocking=True)
         if with_lora:
             ls = [s.req.lora_slot for s in decodes] + [-1] * (bsz - n)
             st["lora"].copy_(self._to_dev(ls, torch.int32), non_blocking=True)
