@@ -53,7 +53,7 @@ API int comm_ipc_close(void* p) { return (int)hipIpcCloseMemHandle(p); }
 API int comm_enable_peer(int dev, int peer) {
   int can = 0;
   if (hipDeviceCanAccessPeer(&can, dev, peer) != hipSuccess || !can) return -1;
-  hipSetDevice(dev);
+  (void)hipSetDevice(dev);
   hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
   return (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) ? 0 : (int)e;
 }
@@ -123,4 +123,205 @@ API int comm_rccl_recv_pages(void* c, void* base, size_t page_bytes, const int64
     }
   }
   return (int)ncclGroupEnd();
+}
+
+// ---------------------------------------------------------------- one-shot all-reduce
+// Tensor-parallel decode steps all-reduce a few hundred KB per layer: latency, not bandwidth.
+// On an xGMI node every GPU reaches every peer over its own link, so instead of a ring (one
+// link in, one link out, world - 1 hops) every rank publishes its operand in a buffer that
+// its peers have mapped through hipIpc and then reads all peers' buffers directly: one hop,
+// all links busy at once, one kernel.
+//
+// Protocol (per workgroup b, which owns a fixed slice of the elements):
+//   1. copy the slice of the operand into the local staging buffer of this call's phase
+//      (two phases alternate, so a rank that is already in call n+1 never overwrites what a
+//      peer still reads for call n: it cannot be in call n+2 before every peer has entered
+//      call n+1, i.e. finished reading call n);
+//   2. release-fence, then store the call's epoch into flag[b][my rank] of every peer;
+//   3. wait until flag[b][r] of the local flags has reached the epoch for every peer r, with a
+//      wall-clock bound: a peer that never arrives sets the error word instead of hanging the
+//      queue; acquire-fence;
+//   4. sum the slice over the ranks in rank order (identical result on every rank) in fp32,
+//      write bf16 into the operand.
+// Epochs live in device memory (one counter per workgroup, advanced by the kernel itself), so
+// the launch is identical every time and can be replayed from a HIP graph.
+#define AR_MAX_RANKS 8
+#define AR_BLOCKS 32
+#define AR_THREADS 512
+#define AR_TIMEOUT_TICKS 200000000ull  // ~2 s of the 100 MHz wall clock
+
+struct ArShared {                       // layout of every rank's published buffer
+  uint32_t flags[AR_BLOCKS][AR_MAX_RANKS];
+  uint32_t pad[256 - AR_MAX_RANKS];     // keep the data 16-byte aligned and off the flag lines
+};
+
+struct ArCtx {
+  int rank, world;
+  size_t max_bytes;
+  char* local;                 // ArShared + 2 * max_bytes
+  char* peers[AR_MAX_RANKS];   // mapped peer buffers (own entry = local)
+  uint32_t* epochs;            // [AR_BLOCKS] device counters
+  int* err;                    // device error word
+};
+
+struct ArArgs {
+  char* peers[AR_MAX_RANKS];
+  uint32_t* epochs;
+  int* err;
+  size_t max_bytes;
+  int rank, world;
+};
+
+__device__ __forceinline__ float ar_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float ar_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t ar_pack(float a, float b) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  bf2 v;
+  v[0] = (__bf16)a;
+  v[1] = (__bf16)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+__global__ __launch_bounds__(AR_THREADS) void ar_oneshot_kernel(ArArgs a, uint16_t* data, long n) {
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  __shared__ uint32_t epoch_s;
+  __shared__ int failed_s;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    epoch_s = a.epochs[b] + 1;
+    failed_s = 0;
+  }
+  __syncthreads();
+  const uint32_t e = epoch_s;
+  const size_t phase_off = sizeof(ArShared) + (size_t)(e & 1u) * a.max_bytes;
+  // slice of 8-element (16-byte) groups owned by this workgroup
+  const long groups = (n + 7) >> 3;
+  const long per = (groups + AR_BLOCKS - 1) / AR_BLOCKS;
+  const long g0 = (long)b * per, g1 = g0 + per < groups ? g0 + per : groups;
+  u4* mine = reinterpret_cast<u4*>(a.peers[a.rank] + phase_off);
+  const u4* src = reinterpret_cast<const u4*>(data);
+  for (long g = g0 + tid; g < g1; g += AR_THREADS) mine[g] = src[g];
+  __threadfence_system();
+  __syncthreads();
+  if (tid < a.world) {
+    ArShared* peer = reinterpret_cast<ArShared*>(a.peers[tid]);
+    __hip_atomic_store(&peer->flags[b][a.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    ArShared* me = reinterpret_cast<ArShared*>(a.peers[a.rank]);
+    const unsigned long long t0 = wall_clock64();
+    while ((int32_t)(__hip_atomic_load(&me->flags[b][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+      if (wall_clock64() - t0 > AR_TIMEOUT_TICKS) {
+        failed_s = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  __threadfence_system();
+  if (failed_s) {
+    if (tid == 0) {
+      *a.err = 1;
+      a.epochs[b] = e;
+    }
+    return;
+  }
+  u4* dst = reinterpret_cast<u4*>(data);
+  for (long g = g0 + tid; g < g1; g += AR_THREADS) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < a.world; ++r) {
+      const u4 v = __builtin_nontemporal_load(reinterpret_cast<const u4*>(a.peers[r] + phase_off) + g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] += ar_lo(v[j]);
+        acc[2 * j + 1] += ar_hi(v[j]);
+      }
+    }
+    u4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = ar_pack(acc[2 * j], acc[2 * j + 1]);
+    dst[g] = o;
+  }
+  if (tid == 0) a.epochs[b] = e;
+}
+
+API void* comm_ar_create(int rank, int world, size_t max_bytes) {
+  bind_thread();
+  if (world < 2 || world > AR_MAX_RANKS || rank < 0 || rank >= world) return nullptr;
+  max_bytes = (max_bytes + 255) & ~(size_t)255;
+  ArCtx* c = new ArCtx();
+  c->rank = rank;
+  c->world = world;
+  c->max_bytes = max_bytes;
+  const size_t total = sizeof(ArShared) + 2 * max_bytes;
+  if (hipMalloc((void**)&c->local, total) != hipSuccess) {
+    delete c;
+    return nullptr;
+  }
+  (void)hipMemset(c->local, 0, total);
+  (void)hipMalloc((void**)&c->epochs, AR_BLOCKS * sizeof(uint32_t));
+  (void)hipMemset(c->epochs, 0, AR_BLOCKS * sizeof(uint32_t));
+  (void)hipMalloc((void**)&c->err, sizeof(int));
+  (void)hipMemset(c->err, 0, sizeof(int));
+  (void)hipDeviceSynchronize();
+  for (int r = 0; r < AR_MAX_RANKS; ++r) c->peers[r] = nullptr;
+  c->peers[rank] = c->local;
+  return c;
+}
+
+API int comm_ar_export(void* ctx, void* handle_out) {
+  return comm_ipc_export(((ArCtx*)ctx)->local, handle_out);
+}
+
+// handles: world entries of comm_ipc_handle_size() bytes, in rank order (own entry ignored).
+API int comm_ar_open(void* ctx, const void* handles) {
+  bind_thread();
+  ArCtx* c = (ArCtx*)ctx;
+  const size_t hs = sizeof(hipIpcMemHandle_t);
+  for (int r = 0; r < c->world; ++r) {
+    if (r == c->rank) continue;
+    void* p = comm_ipc_open((const char*)handles + r * hs);
+    if (p == nullptr) return -1 - r;
+    c->peers[r] = (char*)p;
+  }
+  return 0;
+}
+
+API long comm_ar_max_elems(void* ctx) { return (long)(((ArCtx*)ctx)->max_bytes / 2); }
+
+// In-place sum of `n` bf16 elements (a multiple of 8) at `data` over all ranks; data must be
+// 16-byte aligned.  Returns -1 when the operand does not fit (the caller uses RCCL).
+API int comm_ar_allreduce_bf16(void* ctx, void* data, long n, void* stream) {
+  bind_thread();
+  ArCtx* c = (ArCtx*)ctx;
+  if (n <= 0) return 0;
+  if ((n & 7) || (size_t)n * 2 > c->max_bytes || ((uintptr_t)data & 15)) return -1;
+  ArArgs a;
+  for (int r = 0; r < AR_MAX_RANKS; ++r) a.peers[r] = c->peers[r];
+  a.epochs = c->epochs;
+  a.err = c->err;
+  a.max_bytes = c->max_bytes;
+  a.rank = c->rank;
+  a.world = c->world;
+  hipLaunchKernelGGL(ar_oneshot_kernel, dim3(AR_BLOCKS), dim3(AR_THREADS), 0, (hipStream_t)stream, a,
+                     (uint16_t*)data, n);
+  return 0;
+}
+
+// 1 if any call since creation gave up waiting for a peer (synchronises the device).
+API int comm_ar_failed(void* ctx) {
+  bind_thread();
+  int v = 0;
+  (void)hipMemcpy(&v, ((ArCtx*)ctx)->err, sizeof(int), hipMemcpyDeviceToHost);
+  return v;
+}
+
+API void comm_ar_destroy(void* ctx) {
+  bind_thread();
+  ArCtx* c = (ArCtx*)ctx;
+  for (int r = 0; r < c->world; ++r)
+    if (r != c->rank && c->peers[r]) (void)hipIpcCloseMemHandle(c->peers[r]);
+  (void)hipFree(c->local);
+  (void)hipFree(c->epochs);
+  (void)hipFree(c->err);
+  delete c;
 }

@@ -36,4 +36,8 @@ def init_parallel_from_env(tp_size: int, pp_size: int = 1):
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, init_method="env://")
     init_replica_parallel(tp_size, pp_size)
+    if tp_size > 1 and backend == "nccl" and os.environ.get("VPSA_ONESHOT_ALLREDUCE", "0") == "1":
+        from .state import enable_oneshot_all_reduce
+
+        enable_oneshot_all_reduce(torch.device("cuda", local))
     return get_tp()

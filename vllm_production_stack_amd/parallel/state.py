@@ -30,6 +30,7 @@ class TPGroup:
     size: int = 1
     group: "dist.ProcessGroup | None" = None
     cpu_group: "dist.ProcessGroup | None" = None  # gloo side channel for control messages
+    oneshot: object = None  # OneShotAllReduce when enabled (small bf16 all-reduces)
 
     @property
     def is_driver(self) -> bool:
@@ -148,10 +149,29 @@ def init_replica_parallel(tp_size: int, pp_size: int = 1) -> None:
                                first=base + t, last=base + (pp_size - 1) * tp_size + t))
 
 
+def enable_oneshot_all_reduce(device: torch.device, max_bytes: int = 4 << 20) -> bool:
+    """Map the tensor-parallel peers' published buffers (hipIpc) so that small bf16 all-reduces
+    take the one-shot kernel of ``parallel/oneshot.py``.  All ranks of the group call this."""
+    tp = _TP
+    if tp.size == 1 or device.type != "cuda":
+        return False
+    from .oneshot import OneShotAllReduce
+
+    def exchange(handle: bytes) -> list[bytes]:
+        got: list = [None] * tp.size
+        dist.all_gather_object(got, handle, group=tp.cpu_group)
+        return got
+
+    tp.oneshot = OneShotAllReduce(tp.rank, tp.size, device, exchange, max_bytes)
+    return True
+
+
 def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
     tp = _TP
     if tp.size == 1:
         return x
+    if tp.oneshot is not None and tp.oneshot.fits(x):
+        return tp.oneshot.all_reduce(x)
     nbytes = x.numel() * x.element_size()
     if nbytes >= TWO_SHOT_BYTES and x.shape[0] % tp.size == 0 and x.is_contiguous():
         shard = torch.empty((x.shape[0] // tp.size, *x.shape[1:]), dtype=x.dtype, device=x.device)
