@@ -126,6 +126,10 @@ def main():
     variants = tuple(int(v) for v in a.variants.split(","))
     if "prefill_cold" in cases:
         print(json.dumps(prefill_case("prefill_cold", 1, 8192, 8192, a.iters, variants)), flush=True)
+    if "prefill_first" in cases:  # first chunk of a prompt: purely causal, nothing cached
+        print(json.dumps(prefill_case("prefill_first", 1, 8192, 0, a.iters, variants)), flush=True)
+    if "prefill_last" in cases:  # last chunk of a 21k-token prompt
+        print(json.dumps(prefill_case("prefill_last", 1, 4616, 16384, a.iters, variants)), flush=True)
     if "prefill_warm" in cases:
         print(json.dumps(prefill_case("prefill_warm", 40, 128, 21000, a.iters, variants)), flush=True)
     if "decode" in cases:
