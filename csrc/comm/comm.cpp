@@ -148,7 +148,7 @@ API int comm_rccl_recv_pages(void* c, void* base, size_t page_bytes, const int64
 #define AR_MAX_RANKS 8
 #define AR_BLOCKS 32
 #define AR_THREADS 512
-#define AR_TIMEOUT_TICKS 200000000ull  // ~2 s of the 100 MHz wall clock
+#define AR_TIMEOUT_TICKS 500000000ull  // ~5 s of the 100 MHz wall clock
 
 struct ArShared {                       // layout of every rank's published buffer
   uint32_t flags[AR_BLOCKS][AR_MAX_RANKS];
