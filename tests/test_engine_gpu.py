@@ -244,3 +244,26 @@ def test_sampled_requests_use_the_batched_kernel_and_seeds_reproduce():
     again = eng.generate([prompts[1]], copy.deepcopy(free))[0]
     assert all(len(o) == 12 and all(0 <= t < 1 << 20 for t in o) for o in outs)
     assert outs[1] != again or outs[3] != again  # unseeded draws move on
+
+
+def test_logprobs_for_greedy_and_sampled_rows_on_gpu():
+    eng = gpu_engine("tiny-llama-gqa")
+    ps = prompts(3, 50, seed=4)
+    reqs = [eng.add_request(ps[0], SamplingParams(max_tokens=6, temperature=0, ignore_eos=True, logprobs=4)),
+            eng.add_request(ps[1], SamplingParams(max_tokens=6, temperature=0.9, top_p=0.95, seed=5,
+                                                  ignore_eos=True, logprobs=2)),
+            eng.add_request(ps[2], SamplingParams(max_tokens=6, temperature=0, ignore_eos=True))]
+    seen = {r.request_id: [] for r in reqs}
+    while eng.has_work():
+        for so in eng.step():
+            seen[so.request_id].append(so)
+    a, b, c = (seen[r.request_id] for r in reqs)
+    assert all(so.logprobs is None for so in c)
+    assert sum(len(so.logprobs or []) for so in a) == 6 and sum(len(so.logprobs or []) for so in b) == 6
+    for so in a:  # greedy: the chosen token is the first alternative
+        info = so.logprobs[0]
+        assert info["top_ids"][0] == so.new_token_ids[0] and len(info["top_ids"]) == 4
+        assert abs(info["token_logprob"] - info["top_logprobs"][0]) < 1e-4 and info["token_logprob"] <= 0
+    for so in b:
+        info = so.logprobs[0]
+        assert len(info["top_ids"]) == 2 and info["token_logprob"] <= info["top_logprobs"][0] + 1e-4

@@ -168,3 +168,46 @@ def test_stop_string_truncates():
         assert d["choices"][0]["text"] == " ".join(words[:i]) + " "
         assert d["choices"][0]["finish_reason"] == "stop"
     run(_with_server(fn))
+
+
+def test_logprobs_in_chat_and_completions_stream_and_not():
+    async def fn(s, eng):
+        import math
+
+        body = {"model": "tiny-llama", "messages": [{"role": "user", "content": "tell me"}],
+                "max_tokens": 5, "temperature": 0, "logprobs": True, "top_logprobs": 3, "ignore_eos": True}
+        async with s.post("/v1/chat/completions", json=body) as r:
+            assert r.status == 200
+            d = await r.json()
+        items = d["choices"][0]["logprobs"]["content"]
+        assert len(items) == d["usage"]["completion_tokens"] == 5
+        for it in items:
+            assert it["logprob"] <= 0 and len(it["top_logprobs"]) == 3
+            # greedy: the chosen token is the most likely alternative
+            assert math.isclose(it["logprob"], it["top_logprobs"][0]["logprob"], abs_tol=1e-5)
+            assert it["bytes"] == list(it["token"].encode())
+            assert it["top_logprobs"][0]["logprob"] >= it["top_logprobs"][1]["logprob"]
+        # the same request streamed carries the same numbers
+        got = []
+        async with s.post("/v1/chat/completions", json=dict(body, stream=True)) as r:
+            async for line in r.content:
+                line = line.decode().strip()
+                if line.startswith("data: ") and line != "data: [DONE]":
+                    c = json.loads(line[6:])
+                    for ch in c.get("choices", []):
+                        if ch.get("logprobs"):
+                            got.extend(ch["logprobs"]["content"])
+        assert [round(x["logprob"], 4) for x in got] == [round(x["logprob"], 4) for x in items]
+        # completions shape; sampled request (temperature > 0) reports the model's distribution too
+        body = {"model": "tiny-llama", "prompt": "once upon", "max_tokens": 4, "temperature": 0.8, "seed": 7,
+                "logprobs": 2, "ignore_eos": True}
+        async with s.post("/v1/completions", json=body) as r:
+            d = await r.json()
+        lp = d["choices"][0]["logprobs"]
+        assert len(lp["tokens"]) == len(lp["token_logprobs"]) == len(lp["top_logprobs"]) == len(lp["text_offset"]) == 4
+        assert all(v <= 0 for v in lp["token_logprobs"]) and all(len(t) <= 2 for t in lp["top_logprobs"])
+        # no logprobs asked: the field stays null
+        async with s.post("/v1/completions", json={"model": "tiny-llama", "prompt": "x", "max_tokens": 2}) as r:
+            assert (await r.json())["choices"][0]["logprobs"] is None
+
+    run(_with_server(fn))

@@ -140,7 +140,7 @@ class LLMEngine:
             fresh_pages.extend(self.scheduler.commit(s))
             if id(s) not in sampled:
                 continue
-            tok, _info = sampled[id(s)]
+            tok, info = sampled[id(s)]
             req.output_ids.append(tok)
             self.metrics.generation_tokens.inc()
             t = time.time()
@@ -164,7 +164,8 @@ class LLMEngine:
                 self.metrics.success.inc()
             outputs.append(StepOutput(req.request_id, [tok], reason is not None, reason,
                                       req.prompt_len, len(req.output_ids), req.num_cached_tokens + req.num_external_tokens,
-                                      (req.first_scheduled - req.arrival) if req.first_scheduled else 0.0))
+                                      (req.first_scheduled - req.arrival) if req.first_scheduled else 0.0,
+                                      [info] if info is not None else None))
         if self.connector is not None and fresh_pages:
             self.connector.store_pages(fresh_pages)
         self.metrics.update_scheduler(self.scheduler, self.bm)

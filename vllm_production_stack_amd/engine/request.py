@@ -100,3 +100,4 @@ class StepOutput:
     num_output_tokens: int = 0
     num_cached_tokens: int = 0
     queue_time: float = 0.0  # seconds between arrival and the first scheduled step
+    logprobs: list | None = None  # per new token: {token_logprob, top_ids, top_logprobs}

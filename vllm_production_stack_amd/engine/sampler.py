@@ -49,6 +49,7 @@ class Sampler:
             return ids[:n].tolist(), [None] * n
         out: list[int] = []
         infos: list[dict | None] = []
+        lp_rows: list[int] = []
         greedy_dev = (greedy_ids if greedy_ids is not None else ops.argmax(logits[:n]))[:n]
         batched = self._sample_batched(logits, reqs)  # launched before the greedy ids are read back
         greedy_all = greedy_dev.tolist()
@@ -58,9 +59,15 @@ class Sampler:
                 out.append(greedy_all[i])
                 infos.append(None)
                 continue
-            if i in batched:
+            if i in batched and p.logprobs is None:
                 out.append(batched[i])
                 infos.append(None)
+                continue
+            if not self._needs_penalty(p) and (p.greedy or i in batched):
+                # token already known; its logprobs come from the batched pass below
+                out.append(greedy_all[i] if p.greedy else batched[i])
+                infos.append(None)
+                lp_rows.append(i)
                 continue
             row = logits[i].float()
             if self._needs_penalty(p):
@@ -84,14 +91,36 @@ class Sampler:
                 probs_src = row
             out.append(tok)
             if p.logprobs is not None:
-                lp = torch.log_softmax(probs_src, -1)
+                lp = torch.log_softmax(logits[i].float(), -1)  # the model's distribution, as in the batched pass
                 k = max(1, min(int(p.logprobs), 20))
                 tv, ti = torch.topk(lp, k)
                 infos.append({"token_logprob": float(lp[tok]), "top_ids": ti.tolist(),
                               "top_logprobs": tv.tolist()})
             else:
                 infos.append(None)
+        if lp_rows:
+            for i, info in zip(lp_rows, self._logprobs_batched(logits, lp_rows, [out[i] for i in lp_rows],
+                                                               [reqs[i].params.logprobs for i in lp_rows])):
+                infos[i] = info
         return out, infos
+
+    @staticmethod
+    def _logprobs_batched(logits: torch.Tensor, rows: list[int], toks: list[int], ks: list[int]) -> list[dict]:
+        """Log-probabilities of the model's distribution (log-softmax of the unmodified logits)
+        for the chosen token and the top-k alternatives of every listed row: one pass, one
+        read-back."""
+        dev = logits.device
+        idx = torch.tensor(rows, device=dev)
+        lp = torch.log_softmax(logits.index_select(0, idx).float(), -1)
+        k = max(1, min(20, max(int(x) for x in ks)))
+        tv, ti = torch.topk(lp, k, dim=-1)
+        chosen = lp.gather(1, torch.tensor(toks, device=dev).view(-1, 1)).view(-1)
+        tv, ti, chosen = tv.tolist(), ti.tolist(), chosen.tolist()
+        out = []
+        for j, want in enumerate(ks):
+            n = max(1, min(20, int(want)))
+            out.append({"token_logprob": chosen[j], "top_ids": ti[j][:n], "top_logprobs": tv[j][:n]})
+        return out
 
     def _sample_batched(self, logits: torch.Tensor, reqs: list[Request]) -> dict[int, int]:
         """Rows that only need temperature / top-k / top-p, drawn in one kernel launch.
@@ -100,7 +129,7 @@ class Sampler:
         if not ops.sample_supported(logits) or os.environ.get("VPSA_BATCHED_SAMPLING", "1") == "0":
             return {}
         idx = [i for i, r in enumerate(reqs)
-               if not r.params.greedy and not self._needs_penalty(r.params) and r.params.logprobs is None]
+               if not r.params.greedy and not self._needs_penalty(r.params)]
         if not idx:
             return {}
         params = torch.tensor([[reqs[i].params.temperature, reqs[i].params.top_p,

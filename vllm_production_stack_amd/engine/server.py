@@ -333,6 +333,7 @@ class EngineServer:
     async def _collect(self, rid, ids, params, lora, kvp, span, detok, t0):
         text = ""
         out_ids: list[int] = []
+        lp_infos: list = []
         reason = None
         last = None
         t_first = None
@@ -340,6 +341,8 @@ class EngineServer:
             last = so
             if t_first is None and so.new_token_ids:
                 t_first = time.time()
+            if so.logprobs:
+                lp_infos.extend(so.logprobs)
             new = [t for t in so.new_token_ids if not (so.finished and so.finish_reason == "stop"
                                                        and t in self.engine.eos_ids)]
             out_ids.extend(so.new_token_ids)
@@ -358,7 +361,45 @@ class EngineServer:
         if span is not None:
             self._end_span(span, t0, t_first, len(out_ids), last.num_cached_tokens if last else 0,
                            last.queue_time if last else 0.0, reason or "stop")
+        if lp_infos:
+            usage = dict(usage, _logprobs=lp_infos[:len(out_ids)])  # taken out again by the caller
         return text, out_ids, reason or "stop", usage
+
+    # ------------------------------------------------------------------ logprobs
+    def _tok_text(self, tid: int) -> str:
+        try:
+            return self.engine.tokenizer.decode([int(tid)])
+        except Exception:
+            return ""
+
+    def _chat_logprob_items(self, token_ids: list[int], infos: list) -> list[dict]:
+        """OpenAI chat shape: one entry per generated token with its alternatives."""
+        items = []
+        for tid, info in zip(token_ids, infos):
+            if info is None:
+                continue
+            text = self._tok_text(tid)
+            items.append({
+                "token": text, "logprob": info["token_logprob"], "bytes": list(text.encode("utf-8")),
+                "top_logprobs": [{"token": self._tok_text(a), "logprob": lp,
+                                  "bytes": list(self._tok_text(a).encode("utf-8"))}
+                                 for a, lp in zip(info["top_ids"], info["top_logprobs"])]})
+        return items
+
+    def _completion_logprobs(self, token_ids: list[int], infos: list, offset0: int = 0) -> dict:
+        """OpenAI completions shape: parallel lists."""
+        toks, lps, tops, offs = [], [], [], []
+        off = offset0
+        for tid, info in zip(token_ids, infos):
+            if info is None:
+                continue
+            text = self._tok_text(tid)
+            toks.append(text)
+            lps.append(info["token_logprob"])
+            tops.append({self._tok_text(a): lp for a, lp in zip(info["top_ids"], info["top_logprobs"])})
+            offs.append(off)
+            off += len(text)
+        return {"tokens": toks, "token_logprobs": lps, "top_logprobs": tops, "text_offset": offs}
 
     @staticmethod
     def _stop_hit(text: str, stops: list[str]) -> int | None:
@@ -380,7 +421,7 @@ class EngineServer:
         cid = ("chatcmpl-" if kind == "chat" else "cmpl-") + rid
         obj = "chat.completion.chunk" if kind == "chat" else "text_completion"
 
-        def chunk(delta_text=None, finish=None, role=False, usage=None, choices=True):
+        def chunk(delta_text=None, finish=None, role=False, usage=None, choices=True, logprobs=None):
             d = {"id": cid, "object": obj, "created": created, "model": model}
             if choices:
                 if kind == "chat":
@@ -390,10 +431,10 @@ class EngineServer:
                         delta["content"] = ""
                     if delta_text is not None:
                         delta["content"] = delta_text
-                    d["choices"] = [{"index": 0, "delta": delta, "logprobs": None,
+                    d["choices"] = [{"index": 0, "delta": delta, "logprobs": logprobs,
                                      "finish_reason": finish}]
                 else:
-                    d["choices"] = [{"index": 0, "text": delta_text or "", "logprobs": None,
+                    d["choices"] = [{"index": 0, "text": delta_text or "", "logprobs": logprobs,
                                      "finish_reason": finish}]
             else:
                 d["choices"] = []
@@ -402,6 +443,9 @@ class EngineServer:
             return b"data: " + json.dumps(d, separators=(",", ":")).encode() + b"\n\n"
 
         detok = IncrementalDetokenizer(self.engine.tokenizer)
+        pending_lp: list = []
+        pending_lp_c: dict = {}
+        lp_offset = 0
         n_out = 0
         text = ""
         sent = 0
@@ -416,6 +460,14 @@ class EngineServer:
                 queue_time = so.queue_time
                 if t_first is None and so.new_token_ids:
                     t_first = time.time()
+                if so.logprobs:  # sent with the next text delta (text may lag behind its tokens)
+                    if kind == "chat":
+                        pending_lp.extend(self._chat_logprob_items(so.new_token_ids, so.logprobs))
+                    else:
+                        part = self._completion_logprobs(so.new_token_ids, so.logprobs, lp_offset)
+                        lp_offset += sum(len(t) for t in part["tokens"])
+                        for k2, v2 in part.items():
+                            pending_lp_c.setdefault(k2, []).extend(v2)
                 new = [t for t in so.new_token_ids
                        if not (so.finished and so.finish_reason == "stop" and t in self.engine.eos_ids)]
                 text += detok.push(new)
@@ -429,11 +481,18 @@ class EngineServer:
                 hold = max((len(s) - 1 for s in params.stop), default=0) if reason is None else 0
                 upto = max(sent, len(text) - hold)
                 if upto > sent:
-                    await resp.write(chunk(delta_text=text[sent:upto]))
+                    lp_out = None
+                    if pending_lp:
+                        lp_out, pending_lp = {"content": pending_lp}, []
+                    elif pending_lp_c:
+                        lp_out, pending_lp_c = pending_lp_c, {}
+                    await resp.write(chunk(delta_text=text[sent:upto], logprobs=lp_out))
                     sent = upto
                 if reason is not None:
                     break
-            await resp.write(chunk(delta_text="" if kind == "chat" else "", finish=reason or "stop"))
+            tail_lp = {"content": pending_lp} if pending_lp else (pending_lp_c or None)
+            await resp.write(chunk(delta_text="" if kind == "chat" else "", finish=reason or "stop",
+                                   logprobs=tail_lp))
             if include_usage:
                 usage = {"prompt_tokens": len(ids), "completion_tokens": n_out,
                          "total_tokens": len(ids) + n_out}
@@ -501,6 +560,8 @@ class EngineServer:
             text, out_ids, reason, usage = await self._run_text(rid, ids, params, lora, kvp, span)
         except ValueError as e:
             return _err(400, str(e))
+        lp_infos = usage.pop("_logprobs", None)
+        logprobs = {"content": self._chat_logprob_items(out_ids, lp_infos)} if lp_infos else None
         message = {"role": "assistant", "content": text}
         if body.get("tools") and self.cfg.enable_auto_tool_choice:
             calls, rest = parse_tool_calls(text, self.cfg.tool_call_parser)
@@ -510,7 +571,7 @@ class EngineServer:
         return web.json_response({
             "id": "chatcmpl-" + rid, "object": "chat.completion", "created": int(time.time()),
             "model": model,
-            "choices": [{"index": 0, "message": message, "logprobs": None, "finish_reason": reason}],
+            "choices": [{"index": 0, "message": message, "logprobs": logprobs, "finish_reason": reason}],
             "usage": usage}, headers={"X-Request-Id": rid})
 
     async def completions(self, request):
@@ -528,12 +589,14 @@ class EngineServer:
             text, out_ids, reason, usage = await self._run_text(rid, ids, params, lora, kvp, span)
         except ValueError as e:
             return _err(400, str(e))
+        lp_infos = usage.pop("_logprobs", None)
+        logprobs = self._completion_logprobs(out_ids, lp_infos) if lp_infos else None
         if body.get("echo"):
             text = self.engine.tokenizer.decode(ids) + (" " if text else "") + text
         return web.json_response({
             "id": "cmpl-" + rid, "object": "text_completion", "created": int(time.time()),
             "model": model,
-            "choices": [{"index": 0, "text": text, "logprobs": None, "finish_reason": reason}],
+            "choices": [{"index": 0, "text": text, "logprobs": logprobs, "finish_reason": reason}],
             "usage": usage}, headers={"X-Request-Id": rid})
 
     # ------------------------------------------------------------------ pooling endpoints
