@@ -211,3 +211,50 @@ def test_logprobs_in_chat_and_completions_stream_and_not():
             assert (await r.json())["choices"][0]["logprobs"] is None
 
     run(_with_server(fn))
+
+
+def test_n_choices_and_prompt_lists():
+    async def fn(s, eng):
+        # n sampled choices, seeded: distinct per choice, identical when repeated
+        body = {"model": "tiny-llama", "messages": [{"role": "user", "content": "pick"}], "max_tokens": 6,
+                "temperature": 1.0, "seed": 11, "n": 3, "ignore_eos": True}
+        async with s.post("/v1/chat/completions", json=body) as r:
+            assert r.status == 200
+            d1 = await r.json()
+        async with s.post("/v1/chat/completions", json=body) as r:
+            d2 = await r.json()
+        assert [c["index"] for c in d1["choices"]] == [0, 1, 2]
+        texts = [c["message"]["content"] for c in d1["choices"]]
+        assert texts == [c["message"]["content"] for c in d2["choices"]]
+        assert len(set(texts)) > 1
+        assert d1["usage"]["completion_tokens"] == 18 and d1["usage"]["prompt_tokens"] > 0
+        # streamed: every chunk is tagged with its choice, each choice finishes once
+        finished, seen = [], set()
+        async with s.post("/v1/chat/completions", json=dict(body, stream=True,
+                                                            stream_options={"include_usage": True})) as r:
+            async for line in r.content:
+                line = line.decode().strip()
+                if line.startswith("data: ") and line != "data: [DONE]":
+                    c = json.loads(line[6:])
+                    for ch in c["choices"]:
+                        seen.add(ch["index"])
+                        if ch["finish_reason"]:
+                            finished.append(ch["index"])
+                    if c.get("usage"):
+                        assert c["usage"]["completion_tokens"] == 18
+        assert seen == {0, 1, 2} and sorted(finished) == [0, 1, 2]
+        # greedy with n > 1 is refused; a list of prompts gives one choice per prompt
+        async with s.post("/v1/chat/completions", json=dict(body, temperature=0)) as r:
+            assert r.status == 400
+        body = {"model": "tiny-llama", "prompt": ["first prompt", "second one"], "max_tokens": 3,
+                "temperature": 0, "ignore_eos": True}
+        async with s.post("/v1/completions", json=body) as r:
+            d = await r.json()
+        assert [c["index"] for c in d["choices"]] == [0, 1] and d["usage"]["completion_tokens"] == 6
+        single = []
+        for p in body["prompt"]:
+            async with s.post("/v1/completions", json=dict(body, prompt=p)) as r:
+                single.append((await r.json())["choices"][0]["text"])
+        assert [c["text"] for c in d["choices"]] == single
+
+    run(_with_server(fn))

@@ -411,17 +411,46 @@ class EngineServer:
                     best = i
         return best
 
-    async def _stream(self, request, rid, ids, params, lora, kind, model, include_usage, kvp=None):
-        span = self._request_span(request, rid, ids, params, model)
-        t0, t_first, queue_time, failure = time.time(), None, 0.0, None
+    @staticmethod
+    def _jobs(rid: str, ids_list: list[list[int]], params: SamplingParams):
+        """One generation per (prompt, sample): [(choice index, request id, prompt ids, params)].
+        Sample j of a seeded request uses seed + j, so the n choices differ and reproduce."""
+        import copy
+
+        n = max(1, int(params.n or 1))
+        jobs = []
+        for i, ids in enumerate(ids_list):
+            for j in range(n):
+                index = i * n + j
+                p = params
+                if n > 1:
+                    p = copy.copy(params)
+                    p.n = 1
+                    if params.seed is not None:
+                        p.seed = int(params.seed) + j
+                jobs.append((index, rid if len(ids_list) * n == 1 else f"{rid}-{index}", ids, p))
+        return jobs
+
+    async def _stream(self, request, rid, jobs, lora, kind, model, include_usage, kvp=None):
+        """SSE response; ``jobs`` as built by ``_jobs`` (several choices interleave their chunks,
+        each tagged with its index)."""
+        first_ids, first_params = jobs[0][2], jobs[0][3]
+        span = self._request_span(request, rid, first_ids, first_params, model)
+        t0, failure = time.time(), None
+        tot = {"n_out": 0, "cached": 0, "queue_time": 0.0, "t_first": None, "reason": None}
         resp = web.StreamResponse(status=200, headers={
             "Content-Type": "text/event-stream", "Cache-Control": "no-cache", "X-Request-Id": rid})
         await resp.prepare(request)
         created = int(time.time())
         cid = ("chatcmpl-" if kind == "chat" else "cmpl-") + rid
         obj = "chat.completion.chunk" if kind == "chat" else "text_completion"
+        wlock = asyncio.Lock()
 
-        def chunk(delta_text=None, finish=None, role=False, usage=None, choices=True, logprobs=None):
+        async def send(data: bytes):
+            async with wlock:
+                await resp.write(data)
+
+        def chunk(index=0, delta_text=None, finish=None, role=False, usage=None, choices=True, logprobs=None):
             d = {"id": cid, "object": obj, "created": created, "model": model}
             if choices:
                 if kind == "chat":
@@ -431,10 +460,10 @@ class EngineServer:
                         delta["content"] = ""
                     if delta_text is not None:
                         delta["content"] = delta_text
-                    d["choices"] = [{"index": 0, "delta": delta, "logprobs": logprobs,
+                    d["choices"] = [{"index": index, "delta": delta, "logprobs": logprobs,
                                      "finish_reason": finish}]
                 else:
-                    d["choices"] = [{"index": 0, "text": delta_text or "", "logprobs": logprobs,
+                    d["choices"] = [{"index": index, "text": delta_text or "", "logprobs": logprobs,
                                      "finish_reason": finish}]
             else:
                 d["choices"] = []
@@ -442,24 +471,22 @@ class EngineServer:
                 d["usage"] = usage
             return b"data: " + json.dumps(d, separators=(",", ":")).encode() + b"\n\n"
 
-        detok = IncrementalDetokenizer(self.engine.tokenizer)
-        pending_lp: list = []
-        pending_lp_c: dict = {}
-        lp_offset = 0
-        n_out = 0
-        text = ""
-        sent = 0
-        reason = None
-        cached = 0
-        try:
+        async def run_choice(index, crid, ids, params):
+            detok = IncrementalDetokenizer(self.engine.tokenizer)
+            pending_lp: list = []
+            pending_lp_c: dict = {}
+            lp_offset = 0
+            text = ""
+            sent = 0
+            reason = None
             if kind == "chat":
-                await resp.write(chunk(role=True))
-            async for so in self.ae.generate(rid, ids, params, lora, kvp):
-                n_out += len(so.new_token_ids)
-                cached = so.num_cached_tokens
-                queue_time = so.queue_time
-                if t_first is None and so.new_token_ids:
-                    t_first = time.time()
+                await send(chunk(index, role=True))
+            async for so in self.ae.generate(crid, ids, params, lora, kvp):
+                tot["n_out"] += len(so.new_token_ids)
+                tot["cached"] = max(tot["cached"], so.num_cached_tokens)
+                tot["queue_time"] = max(tot["queue_time"], so.queue_time)
+                if tot["t_first"] is None and so.new_token_ids:
+                    tot["t_first"] = time.time()
                 if so.logprobs:  # sent with the next text delta (text may lag behind its tokens)
                     if kind == "chat":
                         pending_lp.extend(self._chat_logprob_items(so.new_token_ids, so.logprobs))
@@ -478,7 +505,7 @@ class EngineServer:
                 elif so.finished:
                     reason = so.finish_reason
                 # hold back a tail that could still turn into a stop string
-                hold = max((len(s) - 1 for s in params.stop), default=0) if reason is None else 0
+                hold = max((len(x) - 1 for x in params.stop), default=0) if reason is None else 0
                 upto = max(sent, len(text) - hold)
                 if upto > sent:
                     lp_out = None
@@ -486,32 +513,68 @@ class EngineServer:
                         lp_out, pending_lp = {"content": pending_lp}, []
                     elif pending_lp_c:
                         lp_out, pending_lp_c = pending_lp_c, {}
-                    await resp.write(chunk(delta_text=text[sent:upto], logprobs=lp_out))
+                    await send(chunk(index, delta_text=text[sent:upto], logprobs=lp_out))
                     sent = upto
                 if reason is not None:
                     break
             tail_lp = {"content": pending_lp} if pending_lp else (pending_lp_c or None)
-            await resp.write(chunk(delta_text="" if kind == "chat" else "", finish=reason or "stop",
-                                   logprobs=tail_lp))
+            await send(chunk(index, delta_text="", finish=reason or "stop", logprobs=tail_lp))
+            tot["reason"] = reason or "stop"
+
+        tasks = [asyncio.ensure_future(run_choice(*j)) for j in jobs]
+        try:
+            await asyncio.gather(*tasks)
             if include_usage:
-                usage = {"prompt_tokens": len(ids), "completion_tokens": n_out,
-                         "total_tokens": len(ids) + n_out}
-                if cached:
-                    usage["prompt_tokens_details"] = {"cached_tokens": cached}
-                await resp.write(chunk(usage=usage, choices=False))
-            await resp.write(b"data: [DONE]\n\n")
+                n_prompt = sum(len(j[2]) for j in jobs if j[0] % max(1, int(first_params.n or 1)) == 0) \
+                    if len(jobs) > 1 else len(first_ids)
+                usage = {"prompt_tokens": n_prompt, "completion_tokens": tot["n_out"],
+                         "total_tokens": n_prompt + tot["n_out"]}
+                if tot["cached"]:
+                    usage["prompt_tokens_details"] = {"cached_tokens": tot["cached"]}
+                await send(chunk(usage=usage, choices=False))
+            await send(b"data: [DONE]\n\n")
         except (ConnectionResetError, asyncio.CancelledError):
-            self._end_span(span, t0, t_first, n_out, cached, queue_time, "abort", error="client disconnected")
+            for t in tasks:
+                t.cancel()
+            self._end_span(span, t0, tot["t_first"], tot["n_out"], tot["cached"], tot["queue_time"], "abort",
+                           error="client disconnected")
             raise
         except Exception as e:
+            for t in tasks:
+                t.cancel()
             log.exception("stream failed")
             failure = repr(e)
             await resp.write(b"data: " + json.dumps({"error": str(e)}).encode() + b"\n\n")
-        self._end_span(span, t0, t_first, n_out, cached, queue_time, reason or "stop", error=failure)
+        self._end_span(span, t0, tot["t_first"], tot["n_out"], tot["cached"], tot["queue_time"],
+                       tot["reason"] or "stop", error=failure)
         await resp.write_eof()
         return resp
 
+    async def _run_jobs(self, request, rid, jobs, lora, model, kvp):
+        """Non-streaming: run every job, -> [(index, text, out_ids, reason, usage, logprob infos)]
+        in index order plus the summed usage."""
+        async def one(index, crid, ids, params):
+            span = self._request_span(request, crid, ids, params, model)
+            text, out_ids, reason, usage = await self._run_text(crid, ids, params, lora, kvp, span)
+            return index, text, out_ids, reason, usage, usage.pop("_logprobs", None)
+
+        results = await asyncio.gather(*[one(*j) for j in jobs])
+        n = max(1, int(jobs[0][3].n or 1)) if len(jobs) == 1 else None
+        per_prompt = {}
+        for index, crid, ids, params in jobs:
+            per_prompt.setdefault(id(ids), len(ids))
+        n_prompt = sum(per_prompt.values())
+        n_out = sum(len(r[2]) for r in results)
+        usage = {"prompt_tokens": n_prompt, "completion_tokens": n_out, "total_tokens": n_prompt + n_out}
+        cached = max((r[4].get("prompt_tokens_details", {}).get("cached_tokens", 0) for r in results), default=0)
+        if cached:
+            usage["prompt_tokens_details"] = {"cached_tokens": cached}
+        del n
+        return sorted(results, key=lambda r: r[0]), usage
+
     async def _prepare(self, request, kind):
+        """-> ((body, [prompt ids, ...], params, lora, request id), None) or (None, error response).
+        Chat has one prompt; completions accept a string, a token list, or a list of either."""
         try:
             body = await request.json()
         except Exception:
@@ -527,77 +590,84 @@ class EngineServer:
                 msgs = body.get("messages")
                 if not isinstance(msgs, list) or not msgs:
                     return None, _err(400, "'messages' must be a non-empty list")
-                ids = tok.encode_chat(msgs, True, body.get("tools"))
+                ids_list = [tok.encode_chat(msgs, True, body.get("tools"))]
             else:
                 prompt = body.get("prompt", "")
                 if isinstance(prompt, list) and prompt and isinstance(prompt[0], int):
-                    ids = list(prompt)
+                    ids_list = [list(prompt)]
+                elif isinstance(prompt, list) and prompt and isinstance(prompt[0], list):
+                    ids_list = [list(p) for p in prompt]
                 elif isinstance(prompt, list):
-                    ids = tok.encode(str(prompt[0]) if prompt else "")
+                    ids_list = [tok.encode(str(p)) for p in prompt] or [tok.encode("")]
                 else:
-                    ids = tok.encode(str(prompt))
+                    ids_list = [tok.encode(str(prompt))]
         except Exception as e:
             return None, _err(400, f"failed to build prompt: {e}")
-        if len(ids) >= self.engine.max_model_len:
-            return None, _err(400, f"This model's maximum context length is {self.engine.max_model_len} "
-                                   f"tokens. However, you requested {len(ids)} prompt tokens.")
+        for ids in ids_list:
+            if len(ids) >= self.engine.max_model_len:
+                return None, _err(400, f"This model's maximum context length is {self.engine.max_model_len} "
+                                       f"tokens. However, you requested {len(ids)} prompt tokens.")
         params = _sampling_from_body(body, 16 if kind == "completion" else self.engine.max_model_len)
+        if params.n < 1 or params.n * len(ids_list) > 128:
+            return None, _err(400, "'n' times the number of prompts must be between 1 and 128")
+        if params.n > 1 and params.greedy:
+            return None, _err(400, "n > 1 needs temperature > 0 (greedy choices would be identical)")
         rid = request.headers.get("X-Request-Id") or uuid.uuid4().hex
-        return (body, ids, params, lora, rid), None
+        return (body, ids_list, params, lora, rid), None
 
     async def chat(self, request):
         prep, err = await self._prepare(request, "chat")
         if err is not None:
             return err
-        body, ids, params, lora, rid = prep
+        body, ids_list, params, lora, rid = prep
         model = body.get("model") or self.cfg.model_name
         kvp = body.get("kv_transfer_params")
+        jobs = self._jobs(rid, ids_list, params)
         if body.get("stream"):
             inc = bool((body.get("stream_options") or {}).get("include_usage"))
-            return await self._stream(request, rid, ids, params, lora, "chat", model, inc, kvp)
+            return await self._stream(request, rid, jobs, lora, "chat", model, inc, kvp)
         try:
-            span = self._request_span(request, rid, ids, params, model)
-            text, out_ids, reason, usage = await self._run_text(rid, ids, params, lora, kvp, span)
+            results, usage = await self._run_jobs(request, rid, jobs, lora, model, kvp)
         except ValueError as e:
             return _err(400, str(e))
-        lp_infos = usage.pop("_logprobs", None)
-        logprobs = {"content": self._chat_logprob_items(out_ids, lp_infos)} if lp_infos else None
-        message = {"role": "assistant", "content": text}
-        if body.get("tools") and self.cfg.enable_auto_tool_choice:
-            calls, rest = parse_tool_calls(text, self.cfg.tool_call_parser)
-            if calls:
-                message = {"role": "assistant", "content": rest or None, "tool_calls": calls}
-                reason = "tool_calls"
+        choices = []
+        for index, text, out_ids, reason, _u, lp_infos in results:
+            logprobs = {"content": self._chat_logprob_items(out_ids, lp_infos)} if lp_infos else None
+            message = {"role": "assistant", "content": text}
+            if body.get("tools") and self.cfg.enable_auto_tool_choice:
+                calls, rest = parse_tool_calls(text, self.cfg.tool_call_parser)
+                if calls:
+                    message = {"role": "assistant", "content": rest or None, "tool_calls": calls}
+                    reason = "tool_calls"
+            choices.append({"index": index, "message": message, "logprobs": logprobs, "finish_reason": reason})
         return web.json_response({
             "id": "chatcmpl-" + rid, "object": "chat.completion", "created": int(time.time()),
-            "model": model,
-            "choices": [{"index": 0, "message": message, "logprobs": logprobs, "finish_reason": reason}],
-            "usage": usage}, headers={"X-Request-Id": rid})
+            "model": model, "choices": choices, "usage": usage}, headers={"X-Request-Id": rid})
 
     async def completions(self, request):
         prep, err = await self._prepare(request, "completion")
         if err is not None:
             return err
-        body, ids, params, lora, rid = prep
+        body, ids_list, params, lora, rid = prep
         model = body.get("model") or self.cfg.model_name
         kvp = body.get("kv_transfer_params")
+        jobs = self._jobs(rid, ids_list, params)
         if body.get("stream"):
             inc = bool((body.get("stream_options") or {}).get("include_usage"))
-            return await self._stream(request, rid, ids, params, lora, "completion", model, inc, kvp)
+            return await self._stream(request, rid, jobs, lora, "completion", model, inc, kvp)
         try:
-            span = self._request_span(request, rid, ids, params, model)
-            text, out_ids, reason, usage = await self._run_text(rid, ids, params, lora, kvp, span)
+            results, usage = await self._run_jobs(request, rid, jobs, lora, model, kvp)
         except ValueError as e:
             return _err(400, str(e))
-        lp_infos = usage.pop("_logprobs", None)
-        logprobs = self._completion_logprobs(out_ids, lp_infos) if lp_infos else None
-        if body.get("echo"):
-            text = self.engine.tokenizer.decode(ids) + (" " if text else "") + text
+        choices = []
+        for (index, text, out_ids, reason, _u, lp_infos), job in zip(results, jobs):
+            logprobs = self._completion_logprobs(out_ids, lp_infos) if lp_infos else None
+            if body.get("echo"):
+                text = self.engine.tokenizer.decode(job[2]) + (" " if text else "") + text
+            choices.append({"index": index, "text": text, "logprobs": logprobs, "finish_reason": reason})
         return web.json_response({
             "id": "cmpl-" + rid, "object": "text_completion", "created": int(time.time()),
-            "model": model,
-            "choices": [{"index": 0, "text": text, "logprobs": logprobs, "finish_reason": reason}],
-            "usage": usage}, headers={"X-Request-Id": rid})
+            "model": model, "choices": choices, "usage": usage}, headers={"X-Request-Id": rid})
 
     # ------------------------------------------------------------------ pooling endpoints
     async def _embed_ids(self, ids: list[int]) -> list[float]:
