@@ -431,7 +431,7 @@ class EngineServer:
                 jobs.append((index, rid if len(ids_list) * n == 1 else f"{rid}-{index}", ids, p))
         return jobs
 
-    async def _stream(self, request, rid, jobs, lora, kind, model, include_usage, kvp=None):
+    async def _stream(self, request, rid, jobs, lora, kind, model, include_usage, kvp=None, parse_tools=False):
         """SSE response; ``jobs`` as built by ``_jobs`` (several choices interleave their chunks,
         each tagged with its index)."""
         first_ids, first_params = jobs[0][2], jobs[0][3]
@@ -450,7 +450,8 @@ class EngineServer:
             async with wlock:
                 await resp.write(data)
 
-        def chunk(index=0, delta_text=None, finish=None, role=False, usage=None, choices=True, logprobs=None):
+        def chunk(index=0, delta_text=None, finish=None, role=False, usage=None, choices=True, logprobs=None,
+                  tool_calls=None):
             d = {"id": cid, "object": obj, "created": created, "model": model}
             if choices:
                 if kind == "chat":
@@ -460,6 +461,8 @@ class EngineServer:
                         delta["content"] = ""
                     if delta_text is not None:
                         delta["content"] = delta_text
+                    if tool_calls is not None:
+                        delta["tool_calls"] = [dict(c, index=i) for i, c in enumerate(tool_calls)]
                     d["choices"] = [{"index": index, "delta": delta, "logprobs": logprobs,
                                      "finish_reason": finish}]
                 else:
@@ -504,9 +507,12 @@ class EngineServer:
                     reason = "stop"
                 elif so.finished:
                     reason = so.finish_reason
-                # hold back a tail that could still turn into a stop string
+                # hold back a tail that could still turn into a stop string; with tool parsing the
+                # whole answer is held: it is either content or a tool call, known only at the end
                 hold = max((len(x) - 1 for x in params.stop), default=0) if reason is None else 0
                 upto = max(sent, len(text) - hold)
+                if parse_tools:
+                    upto = sent
                 if upto > sent:
                     lp_out = None
                     if pending_lp:
@@ -518,6 +524,18 @@ class EngineServer:
                 if reason is not None:
                     break
             tail_lp = {"content": pending_lp} if pending_lp else (pending_lp_c or None)
+            if parse_tools:
+                calls, rest = parse_tool_calls(text, self.cfg.tool_call_parser)
+                if calls:
+                    if rest:
+                        await send(chunk(index, delta_text=rest))
+                    await send(chunk(index, tool_calls=calls, logprobs=tail_lp))
+                    await send(chunk(index, delta_text=None, finish="tool_calls"))
+                    tot["reason"] = "tool_calls"
+                    return
+                if text:
+                    await send(chunk(index, delta_text=text, logprobs=tail_lp))
+                    tail_lp = None
             await send(chunk(index, delta_text="", finish=reason or "stop", logprobs=tail_lp))
             tot["reason"] = reason or "stop"
 
@@ -590,6 +608,8 @@ class EngineServer:
                 msgs = body.get("messages")
                 if not isinstance(msgs, list) or not msgs:
                     return None, _err(400, "'messages' must be a non-empty list")
+                if body.get("tool_choice") == "none":
+                    body.pop("tools", None)  # the model neither sees the tools nor has its text parsed
                 ids_list = [tok.encode_chat(msgs, True, body.get("tools"))]
             else:
                 prompt = body.get("prompt", "")
@@ -625,7 +645,8 @@ class EngineServer:
         jobs = self._jobs(rid, ids_list, params)
         if body.get("stream"):
             inc = bool((body.get("stream_options") or {}).get("include_usage"))
-            return await self._stream(request, rid, jobs, lora, "chat", model, inc, kvp)
+            return await self._stream(request, rid, jobs, lora, "chat", model, inc, kvp,
+                                      parse_tools=bool(body.get("tools")) and self.cfg.enable_auto_tool_choice)
         try:
             results, usage = await self._run_jobs(request, rid, jobs, lora, model, kvp)
         except ValueError as e:
