@@ -232,10 +232,16 @@ async def rank_main(a: argparse.Namespace) -> None:
                     for p in clients]
         await loop.run_in_executor(None, barrier)
         elapsed = time.time() - t_start
+        # what every replica did in the timed region (shows how evenly the router spread the users)
+        mine = {"rank": rank, "steps": int(engine.prof["steps"]), "busy_s": round(float(engine.prof["t_execute"]), 2),
+                "rows": int(engine.prof["rows"])}
+        per_replica = [mine]
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=gloo)
             elapsed = float(t.item())
+            per_replica = [None] * world
+            dist.all_gather_object(per_replica, mine, group=gloo)
 
         if rank == 0:
             sys.path.insert(0, os.path.join(ROOT, "benchmarks", "multi_round_qa"))
@@ -278,6 +284,7 @@ async def rank_main(a: argparse.Namespace) -> None:
                              if engine.connector is not None and engine.connector.host is not None else None),
                 "engine0_profile": {k: (round(v, 3) if isinstance(v, float) else v)
                                     for k, v in engine.prof.items()},
+                "per_replica": per_replica,
             }
             print(json.dumps(result), flush=True)
         await runner.cleanup()
