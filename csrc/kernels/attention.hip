@@ -58,10 +58,15 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
 
   const int G = n_q / n_kv;
   const int GP = G < 4 ? G : 4;
-  const int groups_per_kv = G / GP;
+  const int groups_per_kv = (G + GP - 1) / GP;
   const int kvh = blockIdx.y / groups_per_kv;
   const int hg = blockIdx.y % groups_per_kv;
-  const int head = kvh * G + hg * GP + (wave % GP);
+  // a group ratio that is not a multiple of GP leaves the last workgroup of a KV head with
+  // fewer query heads than waves: the spare waves recompute the last head (they still feed the
+  // shared K/V tiles and meet every barrier) and write nothing
+  const int head_slot = hg * GP + (wave % GP);
+  const bool head_ok = head_slot < G;
+  const int head = kvh * G + (head_ok ? head_slot : G - 1);
   const int qsub = wave / GP;
 
   const int seq = tile_seq[blockIdx.x];
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
 
   // ---- epilogue: O^T accumulator reg i of half h, tile dt = channel 32dt + 8(i>>2) + 4h + (i&3)
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  if (row_ok) {
+  if (row_ok && head_ok) {
     const float inv = 1.f / l_tot;
     uint16_t* op = out + (long)(row0 + my_row) * out_stride + head * HEAD_DIM;
 #pragma unroll
@@ -274,10 +279,15 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel_v2(
   }
   const int G = n_q / n_kv;
   const int GP = G < 4 ? G : 4;
-  const int groups_per_kv = G / GP;
+  const int groups_per_kv = (G + GP - 1) / GP;
   const int kvh = by / groups_per_kv;
   const int hg = by % groups_per_kv;
-  const int head = kvh * G + hg * GP + (wave % GP);
+  // a group ratio that is not a multiple of GP leaves the last workgroup of a KV head with
+  // fewer query heads than waves: the spare waves recompute the last head (they still feed the
+  // shared K/V tiles and meet every barrier) and write nothing
+  const int head_slot = hg * GP + (wave % GP);
+  const bool head_ok = head_slot < G;
+  const int head = kvh * G + (head_ok ? head_slot : G - 1);
   const int qsub = wave / GP;
 
   const int seq = tile_seq[bx];
@@ -457,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel_v2(
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  if (row_ok) {
+  if (row_ok && head_ok) {
     const float inv = 1.f / l_tot;
     uint16_t* op = out + (long)(row0 + my_row) * out_stride + head * HEAD_DIM;
 #pragma unroll
@@ -493,10 +503,9 @@ VPSA_EXPORT int vpsa_paged_prefill(const void* q, long q_stride, void* out, long
   if (num_tiles <= 0) return 0;
   if (n_q % n_kv != 0) return -1;
   const int G = n_q / n_kv;
-  if (G > 4 && G % 4 != 0) return -1;
-  if (G == 3) return -1;
+  if (G == 3) return -1;  // the tile is 4 waves = GP heads x (4 / GP) row blocks: GP must divide 4
   const int GP = G < 4 ? G : 4;
-  dim3 grid(num_tiles, n_kv * (G / GP)), block(256);
+  dim3 grid(num_tiles, n_kv * ((G + GP - 1) / GP)), block(256);
   const float sl2 = scale * 1.4426950408889634f;
   int variant = g_prefill_variant;
   if (variant < 0) variant = (num_seqs > 0 && num_tiles >= 8 * num_seqs) ? 3 : 2;

@@ -37,7 +37,7 @@ def test_native_library_is_what_runs():
     assert ops.native_loaded(), "libvpsa_kernels.so must be loaded on a GPU box"
 
 
-@pytest.mark.parametrize("model", ["tiny-llama-gqa", "tiny-mixtral"])
+@pytest.mark.parametrize("model", ["tiny-llama-gqa", "tiny-mixtral", "tiny-qwen2"])
 def test_graph_and_eager_decode_agree(model):
     ps = prompts(5, 200, seed=1)
     a = gpu_engine(model).generate(ps, copy.deepcopy(SP))

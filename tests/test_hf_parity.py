@@ -16,8 +16,9 @@ transformers = pytest.importorskip("transformers")
 
 
 def _families():
-    from transformers import (GPT2Config, GPT2LMHeadModel, LlamaConfig, LlamaForCausalLM, MixtralConfig,
-                              MixtralForCausalLM, OPTConfig, OPTForCausalLM)
+    from transformers import (GPT2Config, GPT2LMHeadModel, LlamaConfig, LlamaForCausalLM, MistralConfig,
+                              MistralForCausalLM, MixtralConfig, MixtralForCausalLM, OPTConfig, OPTForCausalLM,
+                              Qwen2Config, Qwen2ForCausalLM)
 
     yield "llama-gqa-rope-scaling", LlamaForCausalLM, LlamaConfig(
         vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=3,
@@ -30,6 +31,13 @@ def _families():
         vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
         num_attention_heads=4, num_key_value_heads=4, max_position_embeddings=512,
         tie_word_embeddings=True, bos_token_id=1, eos_token_id=2)
+    yield "qwen2-qkv-bias", Qwen2ForCausalLM, Qwen2Config(
+        vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+        num_key_value_heads=2, max_position_embeddings=512, rope_theta=1000000.0, rms_norm_eps=1e-6,
+        tie_word_embeddings=True, use_sliding_window=False, bos_token_id=1, eos_token_id=2)
+    yield "mistral", MistralForCausalLM, MistralConfig(
+        vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+        num_key_value_heads=2, max_position_embeddings=512, sliding_window=None, bos_token_id=1, eos_token_id=2)
     yield "mixtral", MixtralForCausalLM, MixtralConfig(
         vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
         num_attention_heads=4, num_key_value_heads=2, num_local_experts=4, num_experts_per_tok=2,

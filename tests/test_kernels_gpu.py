@@ -55,7 +55,7 @@ def test_rmsnorm_strided_input():
     torch.testing.assert_close(y.float(), ref.rms_norm(x, w, 1e-6).float(), atol=2e-2, rtol=2e-2)
 
 
-@pytest.mark.parametrize("n_q,n_kv", [(32, 8), (8, 8), (16, 2)])
+@pytest.mark.parametrize("n_q,n_kv", [(32, 8), (8, 8), (16, 2), (28, 4)])
 def test_rope_and_cache(n_q, n_kv):
     torch.manual_seed(3)
     t, hd, layers, pages = 150, 128, 3, 8
@@ -82,7 +82,7 @@ def _block_tables(n_seqs, max_pages, total_pages, seed):
 
 
 @pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3])
-@pytest.mark.parametrize("n_q,n_kv", [(32, 8), (8, 8), (8, 4), (16, 2)])
+@pytest.mark.parametrize("n_q,n_kv", [(32, 8), (8, 8), (8, 4), (16, 2), (28, 4), (10, 2), (12, 2)])
 def test_paged_prefill_matches_reference(n_q, n_kv, variant):
     torch.manual_seed(4)
     hd, layers = 128, 2
@@ -142,7 +142,7 @@ def test_paged_prefill_forced_rescale():
     assert err < 3e-2, err
 
 
-@pytest.mark.parametrize("n_q,n_kv", [(32, 8), (8, 8), (64, 8)])
+@pytest.mark.parametrize("n_q,n_kv", [(32, 8), (8, 8), (64, 8), (28, 4), (10, 2)])
 @pytest.mark.parametrize("splits", [1, 3, 8])
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_paged_decode_matches_reference(n_q, n_kv, splits, variant):

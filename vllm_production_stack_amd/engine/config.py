@@ -34,6 +34,7 @@ class ModelConfig:
     tie_word_embeddings: bool = False
     num_experts: int = 0
     num_experts_per_tok: int = 0
+    qkv_bias: bool = False  # Qwen2 family, Llama-style checkpoints with attention_bias
     bos_token_id: int = 1
     eos_token_id: int = 2
     extra_eos_token_ids: tuple = ()  # config.json may list several end-of-sequence ids
@@ -124,6 +125,14 @@ PRESETS: dict[str, ModelConfig] = {
     "tiny-llama": ModelConfig(name="tiny-llama"),
     "tiny-llama-gqa": ModelConfig(name="tiny-llama-gqa", num_heads=8, num_kv_heads=2,
                                   hidden_size=512, intermediate_size=1024, num_layers=3),
+    # Qwen2 family: biased q/k/v projections, GQA group of 7 on the 7B model
+    "qwen2.5-7b": ModelConfig(
+        name="qwen2.5-7b", architecture="llama", vocab_size=152064, hidden_size=3584,
+        intermediate_size=18944, num_layers=28, num_heads=28, num_kv_heads=4, head_dim=128,
+        rope_theta=1000000.0, norm_eps=1e-6, max_position_embeddings=32768, qkv_bias=True,
+        bos_token_id=151643, eos_token_id=151645),
+    "tiny-qwen2": ModelConfig(name="tiny-qwen2", num_heads=7, num_kv_heads=1, hidden_size=512,
+                              intermediate_size=1024, num_layers=3, qkv_bias=True, norm_eps=1e-6),
     "tiny-mixtral": ModelConfig(name="tiny-mixtral", architecture="mixtral", num_heads=4,
                                 num_kv_heads=2, hidden_size=256, intermediate_size=256,
                                 num_experts=4, num_experts_per_tok=2),
@@ -141,6 +150,9 @@ _ALIASES = {
     "mistralai/mixtral-8x7b-v0.1": "mixtral-8x7b",
     "mistralai/mixtral-8x7b-instruct-v0.1": "mixtral-8x7b",
     "facebook/opt-125m": "opt-125m",
+    "qwen/qwen2.5-7b-instruct": "qwen2.5-7b",
+    "qwen/qwen2.5-7b": "qwen2.5-7b",
+    "qwen/qwen2-7b-instruct": "qwen2.5-7b",
     "mistralai/mistral-7b-instruct-v0.2": "mistral-7b",
     "mistralai/mistral-7b-v0.1": "mistral-7b",
     "meta-llama/llama-3.3-70b-instruct": "llama-3-70b",
@@ -178,6 +190,8 @@ def _from_hf_config(cfg: dict[str, Any], name: str) -> ModelConfig:
             activation="gelu_new", norm_eps=cfg.get("layer_norm_epsilon", 1e-5),
             bos_token_id=cfg.get("bos_token_id", 50256), eos_token_id=cfg.get("eos_token_id", 50256))
     is_moe = "mixtral" in (arch + mt)
+    if "qwen2" not in (arch + mt) and (cfg.get("attention_bias") or cfg.get("mlp_bias")):
+        raise ValueError(f"{name}: projections with biases are only supported for the Qwen2 family")
     # rotary settings: top-level ``rope_theta`` / ``rope_scaling`` (checkpoints written by
     # transformers 4.x) or one ``rope_parameters`` object (5.x)
     rp = cfg.get("rope_parameters") or {}
@@ -202,7 +216,8 @@ def _from_hf_config(cfg: dict[str, Any], name: str) -> ModelConfig:
         tie_word_embeddings=cfg.get("tie_word_embeddings", False),
         num_experts=cfg.get("num_local_experts", 0),
         num_experts_per_tok=cfg.get("num_experts_per_tok", 0),
-        bos_token_id=cfg.get("bos_token_id", 1), eos_token_id=eos, extra_eos_token_ids=extra_eos)
+        qkv_bias="qwen2" in (arch + mt),
+        bos_token_id=cfg.get("bos_token_id") or 1, eos_token_id=eos, extra_eos_token_ids=extra_eos)
 
 
 def resolve_model(model: str) -> tuple[ModelConfig, Path | None]:

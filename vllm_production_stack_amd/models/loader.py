@@ -107,6 +107,12 @@ def _load_llama(model: TransformerModel, ckpt_dir: Path) -> None:
             lw.wqkv[nq * d:(nq + nkv) * d].copy_(_shard_rows(t, r, s))
         elif sub == "self_attn.v_proj.weight":
             lw.wqkv[(nq + nkv) * d:].copy_(_shard_rows(t, r, s))
+        elif sub == "self_attn.q_proj.bias" and lw.bqkv is not None:
+            lw.bqkv[: nq * d].copy_(_shard_rows(t, r, s))
+        elif sub == "self_attn.k_proj.bias" and lw.bqkv is not None:
+            lw.bqkv[nq * d:(nq + nkv) * d].copy_(_shard_rows(t, r, s))
+        elif sub == "self_attn.v_proj.bias" and lw.bqkv is not None:
+            lw.bqkv[(nq + nkv) * d:].copy_(_shard_rows(t, r, s))
         elif sub == "self_attn.o_proj.weight":
             lw.wo.copy_(_shard_cols(t, r, s))
         elif sub == "mlp.gate_proj.weight":

@@ -27,7 +27,7 @@ from .batch import BatchMeta
 
 
 class LayerWeights:
-    __slots__ = ("ln1", "wqkv", "wo", "ln2", "w_gate_up", "w_down", "router", "w13", "w2")
+    __slots__ = ("ln1", "wqkv", "bqkv", "wo", "ln2", "w_gate_up", "w_down", "router", "w13", "w2")
 
     def __init__(self):
         for s in self.__slots__:
@@ -96,6 +96,12 @@ class TransformerModel:
             wv = self._rand(seed, k + 2, cfg.num_kv_heads * d, h)
             lw.wqkv = torch.cat([rows(wq, nq * d), rows(wk, nkv * d), rows(wv, nkv * d)]).contiguous()
             del wq, wk, wv
+            lw.bqkv = None
+            if cfg.qkv_bias:
+                bq = self._rand(seed, k + 40, cfg.num_heads * d)
+                bk = self._rand(seed, k + 41, cfg.num_kv_heads * d)
+                bv = self._rand(seed, k + 42, cfg.num_kv_heads * d)
+                lw.bqkv = torch.cat([rows(bq, nq * d), rows(bk, nkv * d), rows(bv, nkv * d)]).contiguous()
             wo = self._rand(seed, k + 3, h, cfg.num_heads * d)
             lw.wo = wo[:, r * nq * d:(r + 1) * nq * d].contiguous()
             del wo
@@ -229,7 +235,7 @@ class TransformerModel:
                 x = ops.rms_norm(h, lw.ln1, cfg.norm_eps)
             else:
                 x = ops.rms_norm(h, lw.ln1, cfg.norm_eps, residual)
-            qkv = self._lora("qkv", gl, x, ops.linear(x, lw.wqkv), meta)
+            qkv = self._lora("qkv", gl, x, ops.linear(x, lw.wqkv, lw.bqkv), meta)
             attn = self._attention(qkv, pool, li, meta)
             h = self._lora("o", gl, attn, ops.linear(attn, lw.wo), meta)
             h = tp_all_reduce(h)
