@@ -267,3 +267,21 @@ def test_logprobs_for_greedy_and_sampled_rows_on_gpu():
     for so in b:
         info = so.logprobs[0]
         assert len(info["top_ids"]) == 2 and info["token_logprob"] <= info["top_logprobs"][0] + 1e-4
+
+
+def test_penalties_join_the_batched_kernels_on_gpu():
+    """A presence penalty larger than any logit gap forbids repeating an output token, for greedy
+    and for sampled rows alike; requests without penalties in the same batch are untouched."""
+    eng = gpu_engine("tiny-llama-gqa")
+    ps = prompts(3, 40, seed=6)
+    plain = SamplingParams(max_tokens=24, temperature=0, ignore_eos=True)
+    base = eng.generate([ps[0]], copy.deepcopy(plain))[0]
+    outs = eng.generate(ps, [copy.deepcopy(plain),
+                             SamplingParams(max_tokens=24, temperature=0, presence_penalty=100.0, ignore_eos=True),
+                             SamplingParams(max_tokens=24, temperature=0.8, top_p=0.9, seed=3,
+                                            presence_penalty=100.0, ignore_eos=True)])
+    assert outs[0] == base
+    assert len(set(outs[1])) == len(outs[1]) == 24
+    assert len(set(outs[2])) == len(outs[2]) == 24
+    rep = eng.generate([ps[1]], SamplingParams(max_tokens=24, temperature=0, repetition_penalty=1.5, ignore_eos=True))[0]
+    assert rep != eng.generate([ps[1]], copy.deepcopy(plain))[0] or len(set(rep)) == 24

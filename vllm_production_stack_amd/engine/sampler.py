@@ -2,7 +2,8 @@
 (temperature / top-k / top-p) are drawn by one launch of the batched sampling kernel
 (``csrc/kernels/sampling.hip``: key-threshold bisection instead of a sort, no host round trip
 per row); rows that ask for penalties or logprobs, and CPU tensors, take the per-row PyTorch
-definitions below."""
+definitions below (on the GPU penalties are applied to the logits rows in place first, so those
+rows join the batched kernels too)."""
 
 from __future__ import annotations
 
@@ -34,14 +35,17 @@ class Sampler:
             self._req_gens[req.request_id] = g
         return g
 
-    @staticmethod
-    def _needs_penalty(p) -> bool:
-        return p.presence_penalty != 0 or p.frequency_penalty != 0 or p.repetition_penalty != 1.0
+    _penalized = False  # this step's penalties are already in the logits (GPU path)
+
+    def _needs_penalty(self, p) -> bool:
+        return (not self._penalized) and (p.presence_penalty != 0 or p.frequency_penalty != 0
+                                          or p.repetition_penalty != 1.0)
 
     def sample(self, logits: torch.Tensor, reqs: list[Request],
                greedy_ids: torch.Tensor | None = None) -> tuple[list[int], list[dict | None]]:
         """logits [n, vocab] (row i belongs to reqs[i]) -> (token ids, optional logprob info)."""
         n = len(reqs)
+        self._penalized = False
         all_plain_greedy = all(r.params.greedy and not self._needs_penalty(r.params)
                                and r.params.logprobs is None for r in reqs)
         if all_plain_greedy:
@@ -50,6 +54,19 @@ class Sampler:
         out: list[int] = []
         infos: list[dict | None] = []
         lp_rows: list[int] = []
+        # On the GPU, penalties are written into the logits rows themselves (the buffer is
+        # rewritten by the next step anyway); after that every row is an ordinary row for the
+        # batched kernels and nothing needs the per-row path.
+        self._penalized = False
+        pen_rows = [i for i, r in enumerate(reqs) if self._needs_penalty(r.params)]
+        if pen_rows and ops.sample_supported(logits):
+            idx = torch.tensor(pen_rows, device=logits.device)
+            work = logits.index_select(0, idx).float()
+            for j, i in enumerate(pen_rows):
+                work[j] = self._penalize(work[j], reqs[i])
+            logits.index_copy_(0, idx, work.to(logits.dtype))
+            greedy_ids = None  # computed before the penalties
+            self._penalized = True
         greedy_dev = (greedy_ids if greedy_ids is not None else ops.argmax(logits[:n]))[:n]
         batched = self._sample_batched(logits, reqs)  # launched before the greedy ids are read back
         greedy_all = greedy_dev.tolist()
