@@ -293,3 +293,24 @@ def test_chart_readme_documents_every_schema_key():
             if k2 not in readme and k2[0].upper() + k2[1:] not in readme:
                 missing.append(f"modelSpec.{key}.{k2}")
     assert not missing, missing
+
+
+def test_tutorials_reference_existing_files():
+    """Every repository path a tutorial names exists (values files may be given by bare name)."""
+    import re
+
+    tut = ROOT / "docs" / "tutorials"
+    pages = sorted(tut.glob("*.md"))
+    assert len(pages) >= 20
+    pat = re.compile(r"`((?:deploy|utils|benchmarks|tests|examples|scripts|tools|csrc|profiles|docs)/[A-Za-z0-9_./-]+|"
+                     r"values-[A-Za-z0-9_.-]+\.yaml)`")
+    missing = []
+    for page in pages:
+        for m in pat.finditer(page.read_text()):
+            ref = m.group(1)
+            if not any((ROOT / c).exists() for c in (ref, f"deploy/examples/{ref}")):
+                missing.append(f"{page.name}: {ref}")
+    assert not missing, missing
+    index = (tut / "README.md").read_text()
+    for page in pages:
+        assert page.name == "README.md" or f"({page.name})" in index, f"{page.name} is not linked from the index"
