@@ -175,7 +175,7 @@ def main():
         result["remote_hit_tokens_on_other_replica"] = int(metric(after, "lmcache:num_hit_tokens_total") -
                                                            metric(before, "lmcache:num_hit_tokens_total"))
         cache_stats = http(f"http://127.0.0.1:{other_port}/debug/stats")
-        result["cache_server_seen_by_engine"] = cache_stats.get("remote") if isinstance(cache_stats, dict) else None
+        result["kv_tiers_of_other_replica"] = cache_stats.get("kv_tiers") if isinstance(cache_stats, dict) else None
         # ---- short mixed load through the one router
         t0 = time.time()
         with ThreadPoolExecutor(12) as ex:

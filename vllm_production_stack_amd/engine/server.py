@@ -231,10 +231,11 @@ class EngineServer:
         e = self.engine
         out = {"prof": e.prof, "preemptions": e.scheduler.num_preemptions,
                "prefix_hits": e.bm.hits, "prefix_queries": e.bm.queries,
-               "free_pages": e.bm.num_free(), "graphs": sorted(e.runner._graphs),
+               "free_pages": e.bm.num_free(), "graphs": sorted(e.runner._graphs, key=str),
                "page_bytes": e.runner.page_bytes}
         if e.connector is not None:
             out["pd_push"] = e.connector.pd_stats
+            out["kv_tiers"] = e.connector.tier_stats()
         return web.json_response(out)
 
     # ------------------------------------------------------------------ P->D KV receive side

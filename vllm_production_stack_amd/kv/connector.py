@@ -57,8 +57,10 @@ class KVConnector:
             cap = int((off.max_local_cpu_gb or 5.0) * (1 << 30))
             self.host = HostKVPool(self.pool, cap, on_spill=self._spill)
         self.remote = RemoteKVClient(off.remote_url) if off.remote_url else None
+        self.cfg_remote_url = off.remote_url
         self.remote_known: set[int] = set()
         self.remote_dropped = 0  # fresh pages given up on because the server stopped draining the ring
+        self.loaded_from = {"host": 0, "disk": 0, "remote": 0}  # pages brought back into HBM, by tier
         # Raw (naive) pages of a GPU replica travel through a ring of pinned staging slots:
         # device -> slot on a side stream, slot -> socket on the background thread (and the
         # other way round on load), so the step loop never waits for a host copy or a send.
@@ -155,6 +157,20 @@ class KVConnector:
         self.metrics.kv_hit_tokens.inc(n * PAGE)
         return n
 
+    def tier_stats(self) -> dict:
+        """What the lower tiers hold and have served (for ``GET /debug/stats``)."""
+        out: dict = {"pages_loaded_from": dict(self.loaded_from)}
+        if self.host is not None:
+            out["host"] = {"pages": len(self.host.index), "slots": self.host.n_slots, "stores": self.host.stores,
+                           "loads": self.host.loads, "evictions": self.host.evictions}
+        if self.disk is not None:
+            out["disk"] = {"pages": len(self.disk.index), "bytes": self.disk.bytes}
+        if self.remote is not None:
+            out["remote"] = {"url": self.cfg_remote_url, "pages_known": len(self.remote_known),
+                             "uploads_in_flight": len(self._inflight), "pages_dropped": self.remote_dropped,
+                             "serde": "cachegen" if self.serde.kind else "naive"}
+        return out
+
     def load_pages(self, hashes: list[int], pages: list[int]):
         """Start loading ``hashes`` into HBM ``pages``; returns an event-like object the runner
         fences the compute stream on (or None when the data is already in place)."""
@@ -169,6 +185,7 @@ class KVConnector:
             on_disk = [(h, p) for h, p in slow if self.disk is not None and self.disk.contains(h)]
             fetched = [(h, p) for h, p in slow if (h, p) not in set(on_disk)]
             missing = self._download_staged(fetched)
+            self.loaded_from["remote"] += len(fetched) - len(missing)
             if self.host is not None:
                 done = [x for x in fetched if x not in set(missing)]
                 if done:
@@ -178,6 +195,7 @@ class KVConnector:
             on_disk = [(h, p) for h, p in slow if self.disk is not None and self.disk.contains(h)]
             fetched = [x for x in slow if x not in set(on_disk)]
             missing = self._download_codec(fetched)
+            self.loaded_from["remote"] += len(fetched) - len(missing)
             if self.host is not None:
                 done = [x for x in fetched if x not in set(missing)]
                 if done:
@@ -185,6 +203,7 @@ class KVConnector:
             slow = on_disk + missing
         for h, p in slow:  # disk / remote: decode on this thread, then a plain H2D copy
             t = self.disk.get(h, self.device) if self.disk is not None and self.disk.contains(h) else None
+            self.loaded_from["disk" if t is not None else "remote"] += 1
             if t is None and self.remote is not None:
                 blob = self.remote.get(RemoteKVClient.key(h))
                 for _ in range(100):  # our own upload of this page may still be on its way
@@ -200,6 +219,7 @@ class KVConnector:
             if self.host is not None:
                 self.host.store([(h, p)])
         ev = self.host.load(from_host) if from_host else None
+        self.loaded_from["host"] += len(from_host)
         dt = max(time.time() - t0, 1e-6)
         self.metrics.kv_retrieve_speed.observe(len(hashes) * PAGE / dt)
         if ev is None:
