@@ -39,6 +39,36 @@ API int comm_ipc_export(void* dev_ptr, void* handle_out) {
   return 0;
 }
 
+// Handle of the ALLOCATION that contains dev_ptr plus dev_ptr's offset inside it: a tensor from a
+// caching allocator may sit in the middle of a larger hipMalloc block, and the peer maps the block.
+API int comm_ipc_export_base(void* dev_ptr, void* handle_out, long* offset_out) {
+  bind_thread();
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  hipError_t e = hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)dev_ptr);
+  if (e != hipSuccess || base == nullptr) return (int)(e != hipSuccess ? e : hipErrorInvalidValue);
+  hipIpcMemHandle_t h;
+  e = hipIpcGetMemHandle(&h, (void*)base);
+  if (e != hipSuccess) return (int)e;
+  memcpy(handle_out, &h, sizeof(h));
+  *offset_out = (long)((char*)dev_ptr - (char*)base);
+  return 0;
+}
+
+// A device allocation of its own (not carved from a caching allocator's block), so that the
+// exported handle covers exactly `bytes`.
+API void* comm_dev_alloc(size_t bytes) {
+  bind_thread();
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  return p;
+}
+
+API void comm_dev_free(void* p) {
+  bind_thread();
+  (void)hipFree(p);
+}
+
 API void* comm_ipc_open(const void* handle) {
   bind_thread();
   hipIpcMemHandle_t h;

@@ -147,6 +147,29 @@ def test_ipc_page_push_between_pools():
     assert r.num_cached_tokens == 320 and r.output_ids == want
 
 
+def test_page_push_through_landing_window_in_rounds(monkeypatch):
+    """The hipIpc data plane writes into the decode replica's landing window, which is then copied
+    into pool pages at commit.  A window with fewer slots than the prompt has pages is filled
+    several times; the decode side still finds the whole prompt resident and continues bit-exact."""
+    from vllm_production_stack_amd.parallel.kv_transfer import KVReceiver, local_push
+
+    monkeypatch.setenv("VPSA_PD_LANDING_MIB", "1")
+    src = gpu_engine()
+    dst = gpu_engine()
+    (p,) = prompts(1, 650, seed=10)
+    want = src.generate([p], copy.deepcopy(SP))[0]
+    recv = KVReceiver(dst)
+    pool = dst.runner.pool
+    slots = (1 << 20) // (pool.stride(0) * pool.element_size())
+    assert 1 <= slots < 10, "the test wants several rounds; page size changed?"
+    assert local_push(src, recv, p, window=True) == 10
+    assert len(recv._free_slots) == slots and not recv._slot_of and not recv.reserved
+    r = dst.add_request(p, copy.deepcopy(SP))
+    while dst.has_work():
+        dst.step()
+    assert r.num_cached_tokens == 640 and r.output_ids == want
+
+
 def test_speech_model_bf16_tracks_fp32_on_gpu():
     """Whisper-small shape, random weights: bf16 encoder output and greedy tokens on the GPU
     against the same weights evaluated in fp32."""

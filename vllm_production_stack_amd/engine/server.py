@@ -250,7 +250,7 @@ class EngineServer:
         d = await request.json()
         rcv = self._kv_receiver()
         try:
-            res = await self.ae.call(lambda: rcv.reserve(d["hashes"], int(d["page_bytes"])))
+            res = await self.ae.call(lambda: rcv.reserve(d["hashes"], int(d["page_bytes"]), d))
         except (ValueError, MemoryError) as e:
             return _err(409, str(e), "KVTransferError")
         return web.json_response(res)
@@ -286,7 +286,7 @@ class EngineServer:
     async def kv_commit(self, request):
         d = await request.json()
         rcv = self._kv_receiver()
-        res = await self.ae.call(lambda: rcv.commit(d["hashes"], d["pages"]))
+        res = await self.ae.call(lambda: rcv.commit(d["hashes"], d["pages"], bool(d.get("landed"))))
         return web.json_response(res)
 
     # ------------------------------------------------------------------ LoRA

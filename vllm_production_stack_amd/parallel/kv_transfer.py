@@ -4,8 +4,15 @@ Protocol (control plane = the replicas' own HTTP ports, data plane chosen per pa
   1. producer  POST <decode>/kv/reserve {hashes}      -> {pages, missing, transports...}
      the decode replica allocates HBM pages for the hashes it does not hold yet;
   2. producer  moves the page bytes:
-        ipc   the decode pool is mapped through a hipIpc handle and written with
-              hipMemcpyAsync on a side stream (SDMA over the direct xGMI link),
+        ipc   the decode replica's LANDING WINDOW (a device allocation of its own, a power of
+              two in size, default 4 GiB) is mapped through a hipIpc handle and written with
+              hipMemcpyAsync on a side stream (SDMA over the direct xGMI link); at commit the
+              decode replica copies window slots into its pool pages on the device.  The pool
+              itself is not exported: hipIpcOpenMemHandle was measured to never return for
+              some allocation sizes (6, 7 and 7.03 GiB hang; 4.5, 5, 8, 12, 16, 64, 100 GiB
+              map in under a millisecond; benchmarks/ipc_probe.py), and a pool's size follows
+              from the memory budget.  A request with more pages than free slots goes in
+              rounds (reserve -> push -> commit, repeated),
         rccl  ncclSend / ncclRecv of whole pages on side streams, over a two-rank RCCL
               communicator created per (prefill, decode) pair (the unique id travels over the
               control plane); for GPUs that cannot exchange IPC handles (other node, other
@@ -32,7 +39,7 @@ from .. import _native
 
 log = logging.getLogger("vpsa.kvxfer")
 _comm = None
-_peer_maps: dict[str, tuple[int, int]] = {}  # target url -> (mapped base ptr, page_bytes)
+_peer_maps: dict[tuple[str, str], int] = {}  # (target url, handle) -> mapped base of its landing window
 _rccl_peers: dict[str, tuple[int, str]] = {}  # target url -> (communicator, key on the decode side)
 
 
@@ -62,8 +69,13 @@ def comm():
         lib.comm_ipc_handle_size.restype = c_int
         lib.comm_ipc_export.restype = c_int
         lib.comm_ipc_export.argtypes = [c_void_p, c_void_p]
+        lib.comm_ipc_export_base.restype = c_int
+        lib.comm_ipc_export_base.argtypes = [c_void_p, c_void_p, ctypes.POINTER(ctypes.c_long)]
         lib.comm_ipc_open.restype = c_void_p
         lib.comm_ipc_open.argtypes = [c_void_p]
+        lib.comm_dev_alloc.restype = c_void_p
+        lib.comm_dev_alloc.argtypes = [c_size_t]
+        lib.comm_dev_free.argtypes = [c_void_p]
         lib.comm_ipc_close.argtypes = [c_void_p]
         lib.comm_push_pages.restype = c_int
         lib.comm_push_pages.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p]
@@ -101,18 +113,20 @@ def _post(url: str, payload: dict, raw: bytes | None = None, timeout: float = 60
     return json.loads(body) if body else {}
 
 
-def export_ipc_handle(pool: torch.Tensor) -> str | None:
-    """Hex hipIpc handle of the KV pool allocation (decode side)."""
+def export_ipc_handle(pool: torch.Tensor) -> tuple[str, int] | None:
+    """(hex hipIpc handle of the device allocation that contains the KV pool, byte offset of the
+    pool inside that allocation).  The caching allocator may place the pool in the middle of a
+    larger block; the peer maps the whole block and adds the offset."""
     if not pool.is_cuda:
         return None
     try:
         lib = comm()
         n = lib.comm_ipc_handle_size()
         buf = ctypes.create_string_buffer(n)
-        base = pool.untyped_storage().data_ptr()
-        if lib.comm_ipc_export(c_void_p(base), buf) != 0:
+        off = ctypes.c_long(0)
+        if lib.comm_ipc_export_base(c_void_p(pool.data_ptr()), buf, ctypes.byref(off)) != 0:
             return None
-        return buf.raw.hex()
+        return buf.raw.hex(), int(off.value)
     except Exception as e:
         log.warning("hipIpc export failed: %s", e)
         return None
@@ -123,37 +137,41 @@ def push_request_pages(engine, target: str, hashes: list[int], pages: list[int])
     runner = engine.runner
     pool = runner.pool
     page_bytes = pool.stride(0) * pool.element_size()
-    res = _post(target + "/kv/reserve", {"hashes": hashes, "page_bytes": page_bytes,
-                                         "source_rank": _my_rank()})
-    dst_pages = res.get("pages", [])
-    missing = res.get("missing", [])
-    if not missing:
-        return "resident"
     idx = {h: i for i, h in enumerate(hashes)}
-    src = [pages[idx[h]] for h in missing]
-    mode = "tcp"
     pref = transport_preference()
-    same_host = res.get("host_id") == host_identity()
-    if pool.is_cuda and pref in ("auto", "ipc") and res.get("ipc_handle") and same_host:
-        try:
-            _push_ipc(pool, target, res["ipc_handle"], res.get("pool_offset", 0), page_bytes, src, dst_pages)
-            mode = "ipc"
-        except Exception as e:
-            log.warning("ipc push failed (%s); falling back", e)
-    if mode == "tcp" and pool.is_cuda and pref == "rccl" and res.get("gpu"):
-        try:
-            _push_rccl(pool, target, page_bytes, src, dst_pages)
-            mode = "rccl"
-        except Exception as e:
-            log.warning("rccl push failed (%s); falling back to tcp", e)
-    if mode == "tcp":
-        chunk = 8
-        for i in range(0, len(src), chunk):
-            blob = pool[torch.tensor(src[i:i + chunk], device=pool.device)].contiguous().cpu()
-            raw = blob.view(torch.uint8).numpy().tobytes()
-            _post(target + "/kv/push", {"pages": dst_pages[i:i + chunk], "page_bytes": page_bytes}, raw)
-    _post(target + "/kv/commit", {"hashes": missing, "pages": dst_pages})
-    return mode
+    used = "resident"
+    for _ in range(len(hashes) + 2):  # one round per landing-window fill; bounded in any case
+        res = _post(target + "/kv/reserve", {"hashes": hashes, "page_bytes": page_bytes, "source_rank": _my_rank(),
+                                             "host_id": host_identity(), "transport": pref, "gpu": bool(pool.is_cuda)})
+        dst_pages = res.get("pages", [])
+        missing = res.get("missing", [])
+        if not missing:
+            break
+        src = [pages[idx[h]] for h in missing]
+        mode = "tcp"
+        if pool.is_cuda and res.get("ipc_handle") and res.get("ipc_slots") is not None:
+            try:
+                _push_ipc(pool, target, res["ipc_handle"], res.get("ipc_offset", 0), page_bytes, src, res["ipc_slots"])
+                mode = "ipc"
+            except Exception as e:
+                log.warning("ipc push failed (%s); falling back", e)
+        if mode == "tcp" and pool.is_cuda and pref == "rccl" and res.get("gpu"):
+            try:
+                _push_rccl(pool, target, page_bytes, src, dst_pages)
+                mode = "rccl"
+            except Exception as e:
+                log.warning("rccl push failed (%s); falling back to tcp", e)
+        if mode == "tcp":
+            chunk = 8
+            for i in range(0, len(src), chunk):
+                blob = pool[torch.tensor(src[i:i + chunk], device=pool.device)].contiguous().cpu()
+                raw = blob.view(torch.uint8).numpy().tobytes()
+                _post(target + "/kv/push", {"pages": dst_pages[i:i + chunk], "page_bytes": page_bytes}, raw)
+        _post(target + "/kv/commit", {"hashes": missing, "pages": dst_pages, "landed": mode == "ipc"})
+        used = mode
+        if not res.get("more"):
+            break
+    return used
 
 
 def _my_rank() -> int:
@@ -162,22 +180,22 @@ def _my_rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else -1
 
 
-def _push_ipc(pool, target, handle_hex, pool_offset, page_bytes, src_pages, dst_pages) -> None:
+def _push_ipc(pool, target, handle_hex, offset, page_bytes, src_pages, dst_slots) -> None:
+    """Copy pool pages into slots of the peer's landing window."""
     lib = comm()
-    ent = _peer_maps.get(target)
-    if ent is None:
+    base = _peer_maps.get((target, handle_hex))
+    if base is None:
         h = bytes.fromhex(handle_hex)
         base = lib.comm_ipc_open(ctypes.create_string_buffer(h, len(h)))
         if not base:
             raise RuntimeError("hipIpcOpenMemHandle failed")
-        ent = (base, page_bytes)
-        _peer_maps[target] = ent
+        _peer_maps[(target, handle_hex)] = base
     n = len(src_pages)
     sp = (ctypes.c_int64 * n)(*src_pages)
-    dp = (ctypes.c_int64 * n)(*dst_pages)
+    dp = (ctypes.c_int64 * n)(*dst_slots)
     stream = torch.cuda.Stream(device=pool.device)
     stream.wait_stream(torch.cuda.current_stream(pool.device))
-    rc = lib.comm_push_pages(c_void_p(pool.data_ptr()), c_void_p(ent[0] + pool_offset), page_bytes,
+    rc = lib.comm_push_pages(c_void_p(pool.data_ptr()), c_void_p(base + offset), page_bytes,
                              sp, dp, n, c_void_p(stream.cuda_stream))
     if rc != 0:
         raise RuntimeError(f"comm_push_pages failed ({rc})")
@@ -232,27 +250,65 @@ class KVReceiver:
     def __init__(self, engine):
         self.engine = engine
         self.reserved: dict[int, int] = {}  # hash -> page reserved for an in-flight transfer
-        self._handle = None
+        self._landing = None  # device pointer of the landing window (0: could not be set up)
+        self._landing_handle = None
+        self._free_slots: list[int] = []
+        self._slot_of: dict[int, int] = {}  # hash -> landing slot of an in-flight ipc transfer
         self._rccl: dict[str, int] = {}  # unique id (hex) -> communicator with one prefill replica
         self._rccl_stream = None
 
-    def reserve(self, hashes: list[int], page_bytes: int) -> dict:
+    def _landing_window(self, page_bytes: int) -> bool:
+        """Allocate and export the landing window on first use; False when there is none."""
+        if self._landing is None:
+            import os
+
+            self._landing = 0
+            nbytes = 1 << max(int(os.environ.get("VPSA_PD_LANDING_MIB", "4096")) << 20, 1).bit_length() - 1
+            lib = comm()
+            ptr = lib.comm_dev_alloc(c_size_t(nbytes)) if nbytes >= page_bytes else None
+            if ptr:
+                buf = ctypes.create_string_buffer(lib.comm_ipc_handle_size())
+                if lib.comm_ipc_export(c_void_p(ptr), buf) == 0:
+                    self._landing, self._landing_handle = ptr, buf.raw.hex()
+                    self._free_slots = list(range(nbytes // page_bytes))
+                    log.info("P/D landing window: %d MiB, %d page slots", nbytes >> 20, len(self._free_slots))
+                else:
+                    lib.comm_dev_free(c_void_p(ptr))
+            if not self._landing:
+                log.warning("no hipIpc landing window (allocation or export failed): pages arrive by RCCL or TCP")
+        return bool(self._landing)
+
+    def reserve(self, hashes: list[int], page_bytes: int, peer: dict | None = None) -> dict:
+        """``peer``: what the producer said about itself (host_id, transport, gpu); a producer on
+        this host with a GPU gets landing-window slots, as many pages as there are free slots."""
         bm = self.engine.bm
         pool = self.engine.runner.pool
         mine = pool.stride(0) * pool.element_size()
         if page_bytes != mine:
             raise ValueError(f"page size mismatch: sender {page_bytes}, receiver {mine}")
         missing = [h for h in hashes if not bm.contains(h) and h not in self.reserved]
+        peer = peer or {}
+        slots = None
+        more = False
+        by_ipc = bool(missing and pool.is_cuda and peer.get("gpu") and peer.get("host_id") == host_identity() and
+                      peer.get("transport", "auto") in ("auto", "ipc") and self._landing_window(page_bytes) and
+                      self._free_slots)
+        if by_ipc:
+            k = min(len(missing), len(self._free_slots))
+            more = k < len(missing)
+            missing = missing[:k]
         if missing and not bm.can_allocate(len(missing)):
             raise MemoryError("decode replica has no free KV pages for the transfer")
+        if by_ipc:
+            slots = [self._free_slots.pop() for _ in missing]
         pages = bm.allocate(len(missing)) if missing else []
-        for h, p in zip(missing, pages):
+        for i, (h, p) in enumerate(zip(missing, pages)):
             self.reserved[h] = p
-        if self._handle is None:
-            self._handle = export_ipc_handle(pool) or ""
-        return {"pages": pages, "missing": missing, "ipc_handle": self._handle or None,
-                "pool_offset": pool.data_ptr() - pool.untyped_storage().data_ptr() if pool.is_cuda else 0,
-                "host_id": host_identity(), "gpu": bool(pool.is_cuda)}
+            if slots is not None:
+                self._slot_of[h] = slots[i]
+        return {"pages": pages, "missing": missing, "more": more,
+                "ipc_handle": self._landing_handle if slots is not None else None, "ipc_offset": 0,
+                "ipc_slots": slots, "host_id": host_identity(), "gpu": bool(pool.is_cuda)}
 
     def rccl_init(self, key: str) -> dict:
         """Join the two-rank communicator a prefill replica is creating (blocks until it joined)."""
@@ -289,10 +345,27 @@ class KVReceiver:
         pool[torch.tensor(pages, device=pool.device)] = t.to(pool.device)
         return {"ok": True}
 
-    def commit(self, hashes: list[int], pages: list[int]) -> dict:
+    def commit(self, hashes: list[int], pages: list[int], landed: bool = False) -> dict:
+        """Publish transferred pages.  ``landed``: the bytes are in the landing window (the
+        producer has synchronised its copy stream); they move into the pool pages first.  Slots
+        are returned either way."""
         bm = self.engine.bm
+        pool = self.engine.runner.pool
+        slots = [self._slot_of.pop(h, None) for h in hashes]
+        if landed:
+            if any(s is None for s in slots):
+                raise ValueError("commit of landed pages without landing slots")
+            n = len(pages)
+            sp = (ctypes.c_int64 * n)(*slots)
+            dp = (ctypes.c_int64 * n)(*pages)
+            rc = comm().comm_push_pages(c_void_p(self._landing), c_void_p(pool.data_ptr()),
+                                        pool.stride(0) * pool.element_size(), sp, dp, n,
+                                        c_void_p(torch.cuda.current_stream(pool.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError(f"landing window copy failed ({rc})")
         if self.engine.runner.device.type == "cuda":
             torch.cuda.synchronize()
+        self._free_slots.extend(s for s in slots if s is not None)
         for h, p in zip(hashes, pages):
             self.reserved.pop(h, None)
             bm.register(p, h)
@@ -300,11 +373,13 @@ class KVReceiver:
         return {"ok": True, "published": len(pages)}
 
 
-def local_push(src_engine, receiver: "KVReceiver", prompt_ids: list[int]) -> int:
+def local_push(src_engine, receiver: "KVReceiver", prompt_ids: list[int], window: bool = False) -> int:
     """Same-process P->D transfer (two engines sharing a device or both on the CPU): the
     reserve/push/commit protocol with the HTTP hops removed.  On a GPU the bytes move with the
     same side-stream page copier the hipIpc data plane uses, so this exercises
-    ``comm_push_pages`` without a second process.  Returns the number of pages moved."""
+    ``comm_push_pages`` without a second process; ``window`` sends them through the receiver's
+    landing window, in rounds when it has fewer slots than there are pages (its device pointer
+    is used directly: a process cannot open its own hipIpc handle).  Returns the pages moved."""
     from ..engine.block_manager import chain_hashes
 
     bm = src_engine.bm
@@ -314,28 +389,39 @@ def local_push(src_engine, receiver: "KVReceiver", prompt_ids: list[int]) -> int
     if not hashes:
         return 0
     pages = bm.match_prefix(hashes, count_stats=False)  # takes a reference on each page
+    moved = 0
     try:
         spool, dpool = src_engine.runner.pool, receiver.engine.runner.pool
         page_bytes = spool.stride(0) * spool.element_size()
-        res = receiver.reserve(hashes, page_bytes)
-        missing, dst = res["missing"], res["pages"]
         idx = {h: i for i, h in enumerate(hashes)}
-        src = [pages[idx[h]] for h in missing]
-        if missing and spool.is_cuda:
-            n = len(src)
-            sp = (ctypes.c_int64 * n)(*src)
-            dp = (ctypes.c_int64 * n)(*dst)
-            stream = torch.cuda.Stream(device=spool.device)
-            stream.wait_stream(torch.cuda.current_stream(spool.device))
-            rc = comm().comm_push_pages(c_void_p(spool.data_ptr()), c_void_p(dpool.data_ptr()),
-                                        page_bytes, sp, dp, n, c_void_p(stream.cuda_stream))
-            if rc != 0:
-                raise RuntimeError(f"comm_push_pages failed ({rc})")
-            stream.synchronize()
-        elif missing:
-            dpool[torch.tensor(dst)] = spool[torch.tensor(src)]
-        if missing:
-            receiver.commit(missing, dst)
-        return len(missing)
+        peer = {"gpu": True, "host_id": host_identity(), "transport": "ipc"} if window else None
+        for _ in range(len(hashes) + 2):
+            res = receiver.reserve(hashes, page_bytes, peer)
+            missing, dst = res["missing"], res["pages"]
+            if not missing:
+                break
+            src = [pages[idx[h]] for h in missing]
+            landed = res.get("ipc_slots") is not None
+            if window and not landed:
+                raise RuntimeError("the receiver offered no landing window")
+            if spool.is_cuda:
+                n = len(src)
+                sp = (ctypes.c_int64 * n)(*src)
+                dp = (ctypes.c_int64 * n)(*(res["ipc_slots"] if landed else dst))
+                base = receiver._landing if landed else dpool.data_ptr()
+                stream = torch.cuda.Stream(device=spool.device)
+                stream.wait_stream(torch.cuda.current_stream(spool.device))
+                rc = comm().comm_push_pages(c_void_p(spool.data_ptr()), c_void_p(base),
+                                            page_bytes, sp, dp, n, c_void_p(stream.cuda_stream))
+                if rc != 0:
+                    raise RuntimeError(f"comm_push_pages failed ({rc})")
+                stream.synchronize()
+            else:
+                dpool[torch.tensor(dst)] = spool[torch.tensor(src)]
+            receiver.commit(missing, dst, landed)
+            moved += len(missing)
+            if not res.get("more"):
+                break
+        return moved
     finally:
         bm.free(pages)
