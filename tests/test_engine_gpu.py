@@ -164,6 +164,14 @@ def test_page_push_through_landing_window_in_rounds(monkeypatch):
     assert 1 <= slots < 10, "the test wants several rounds; page size changed?"
     assert local_push(src, recv, p, window=True) == 10
     assert len(recv._free_slots) == slots and not recv._slot_of and not recv.reserved
+    # every slot held by other producers: the reserve says so instead of handing out pool pages
+    from vllm_production_stack_amd.parallel.kv_transfer import host_identity
+
+    held, recv._free_slots = recv._free_slots, []
+    busy = recv.reserve([1, 2, 3], pool.stride(0) * pool.element_size(),
+                        {"gpu": True, "host_id": host_identity(), "transport": "auto"})
+    assert busy.get("busy") and not busy["pages"] and not recv.reserved
+    recv._free_slots = held
     r = dst.add_request(p, copy.deepcopy(SP))
     while dst.has_work():
         dst.step()

@@ -5,7 +5,7 @@ Protocol (control plane = the replicas' own HTTP ports, data plane chosen per pa
      the decode replica allocates HBM pages for the hashes it does not hold yet;
   2. producer  moves the page bytes:
         ipc   the decode replica's LANDING WINDOW (a device allocation of its own, a power of
-              two in size, default 4 GiB) is mapped through a hipIpc handle and written with
+              two in size: LMCACHE_NIXL_BUFFER_SIZE, default 1 GiB) is mapped through a hipIpc handle and written with
               hipMemcpyAsync on a side stream (SDMA over the direct xGMI link); at commit the
               decode replica copies window slots into its pool pages on the device.  The pool
               itself is not exported: hipIpcOpenMemHandle was measured to never return for
@@ -140,9 +140,18 @@ def push_request_pages(engine, target: str, hashes: list[int], pages: list[int])
     idx = {h: i for i, h in enumerate(hashes)}
     pref = transport_preference()
     used = "resident"
-    for _ in range(len(hashes) + 2):  # one round per landing-window fill; bounded in any case
+    import time
+
+    rounds, deadline = 0, time.time() + 20.0
+    while rounds < len(hashes) + 2:  # one round per landing-window fill; bounded in any case
         res = _post(target + "/kv/reserve", {"hashes": hashes, "page_bytes": page_bytes, "source_rank": _my_rank(),
                                              "host_id": host_identity(), "transport": pref, "gpu": bool(pool.is_cuda)})
+        if res.get("busy"):  # the window is full of other producers' pages
+            if time.time() > deadline:
+                pref = "tcp"  # the next reserve asks for pool pages and the bytes go over the control plane
+            time.sleep(0.002)
+            continue
+        rounds += 1
         dst_pages = res.get("pages", [])
         missing = res.get("missing", [])
         if not missing:
@@ -263,7 +272,12 @@ class KVReceiver:
             import os
 
             self._landing = 0
-            nbytes = 1 << max(int(os.environ.get("VPSA_PD_LANDING_MIB", "4096")) << 20, 1).bit_length() - 1
+            # the chart's nixlBufferSize (LMCACHE_NIXL_BUFFER_SIZE, 1 GiB in every reference example:
+            # /root/reference/.github/values-10-disagg-prefill.yaml:32) is this window's size
+            want = getattr(getattr(self.engine.cfg, "kv_offload", None), "pd_buffer_bytes", 1 << 30)
+            if os.environ.get("VPSA_PD_LANDING_MIB"):
+                want = int(os.environ["VPSA_PD_LANDING_MIB"]) << 20
+            nbytes = 1 << max(int(want), 1).bit_length() - 1  # largest power of two that fits
             lib = comm()
             ptr = lib.comm_dev_alloc(c_size_t(nbytes)) if nbytes >= page_bytes else None
             if ptr:
@@ -291,8 +305,11 @@ class KVReceiver:
         slots = None
         more = False
         by_ipc = bool(missing and pool.is_cuda and peer.get("gpu") and peer.get("host_id") == host_identity() and
-                      peer.get("transport", "auto") in ("auto", "ipc") and self._landing_window(page_bytes) and
-                      self._free_slots)
+                      peer.get("transport", "auto") in ("auto", "ipc") and self._landing_window(page_bytes))
+        if by_ipc and not self._free_slots:
+            # other producers fill the window right now: their commits free it within milliseconds
+            return {"pages": [], "missing": [], "more": True, "busy": True, "host_id": host_identity(),
+                    "gpu": True}
         if by_ipc:
             k = min(len(missing), len(self._free_slots))
             more = k < len(missing)
