@@ -1,0 +1,52 @@
+"""bench.py's contract, rehearsed on the CPU: launched the way the multi-GPU run launches it
+(``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W``),
+rank 0 prints exactly one JSON line with the agreed fields, the value is the aggregate over replicas
+and every replica served part of the load.  Tiny model, gloo."""
+
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--device", "cpu", "--model", "tiny-llama", "--users-per-gpu", "3", "--warmup-users-per-gpu", "1",
+         "--sys-len", "40", "--history-len", "200", "--answer-len", "8", "--max-model-len", "2048",
+         "--max-num-batched-tokens", "512"]
+FIELDS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+          "vs_baseline", "dtype", "data", "config")
+
+
+def _one_json_line(stdout: str) -> dict:
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_under_torchrun():
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29733", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1"] + SMALL
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = _one_json_line(p.stdout)
+    for f in FIELDS:
+        assert f in res, f
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["warmup"] == 1
+    assert res["higher_is_better"] is True and res["scaling"] == "weak" and res["unit"] == "tokens/s"
+    assert res["config"]["global_batch"] == 6 and res["requests"] == 12 and res["failed_requests"] == 0
+    assert res["value"] > 0 and abs(res["ms_per_step"] - res["elapsed_s"] / 2 * 1e3) < 1.0
+    assert len(res["per_replica"]) == 2 and all(r["rows"] > 0 for r in res["per_replica"])
+
+
+def test_single_process_defaults_to_one_gpu():
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                        "--base-port", "19860"] + SMALL, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = _one_json_line(p.stdout)
+    assert res["n_gpus"] == 1 and res["config"]["global_batch"] == 3 and res["failed_requests"] == 0
