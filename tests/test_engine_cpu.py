@@ -216,3 +216,27 @@ def test_latency_aware_prefill_admission_splits_a_burst_of_follow_up_turns():
     burst(alone, 1, 3000)  # 300 ms estimated: still scheduled (the first prefill always is)
     out = alone.schedule()
     assert [s.n for s in out.prefills] == [3000]
+
+
+def test_kv_transfer_reservations_expire_when_the_producer_never_commits():
+    """A prefill replica that dies between /kv/reserve and /kv/commit must not keep the decode
+    replica's pages: the reservation is dropped after its TTL, and a late commit is refused."""
+    import time
+
+    from vllm_production_stack_amd.parallel.kv_transfer import KVReceiver
+
+    eng = make_engine(pages=16)
+    recv = KVReceiver(eng)
+    recv.reserve_ttl = 0.05
+    pool = eng.runner.pool
+    page_bytes = pool.stride(0) * pool.element_size()
+    free0 = eng.bm.num_free()
+    res = recv.reserve([11, 12, 13], page_bytes)
+    assert len(res["pages"]) == 3 and eng.bm.num_free() == free0 - 3
+    time.sleep(0.1)
+    again = recv.reserve([21], page_bytes)  # any later reserve sweeps
+    assert eng.bm.num_free() == free0 - 1 and not any(h in recv.reserved for h in (11, 12, 13))
+    with pytest.raises(ValueError):
+        recv.commit([11, 12, 13], res["pages"])
+    recv.commit([21], again["pages"])
+    assert eng.bm.contains(21) and not recv.reserved and not recv._reserved_at

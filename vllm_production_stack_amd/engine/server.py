@@ -286,7 +286,10 @@ class EngineServer:
     async def kv_commit(self, request):
         d = await request.json()
         rcv = self._kv_receiver()
-        res = await self.ae.call(lambda: rcv.commit(d["hashes"], d["pages"], bool(d.get("landed"))))
+        try:
+            res = await self.ae.call(lambda: rcv.commit(d["hashes"], d["pages"], bool(d.get("landed"))))
+        except ValueError as e:
+            return _err(409, str(e), "KVTransferError")
         return web.json_response(res)
 
     # ------------------------------------------------------------------ LoRA

@@ -263,6 +263,11 @@ class KVReceiver:
         self._landing_handle = None
         self._free_slots: list[int] = []
         self._slot_of: dict[int, int] = {}  # hash -> landing slot of an in-flight ipc transfer
+        self._reserved_at: dict[int, float] = {}  # hash -> time of its reserve
+        import os
+
+        # a producer that died between reserve and commit must not keep pages and window slots
+        self.reserve_ttl = float(os.environ.get("VPSA_PD_RESERVE_TTL_S", "120"))
         self._rccl: dict[str, int] = {}  # unique id (hex) -> communicator with one prefill replica
         self._rccl_stream = None
 
@@ -292,6 +297,24 @@ class KVReceiver:
                 log.warning("no hipIpc landing window (allocation or export failed): pages arrive by RCCL or TCP")
         return bool(self._landing)
 
+    def _expire(self) -> int:
+        """Give back pages and window slots of reservations nobody committed within the TTL."""
+        import time
+
+        now = time.time()
+        old = [h for h, t in self._reserved_at.items() if now - t > self.reserve_ttl]
+        for h in old:
+            self._reserved_at.pop(h, None)
+            page = self.reserved.pop(h, None)
+            if page is not None:
+                self.engine.bm.free([page])
+            slot = self._slot_of.pop(h, None)
+            if slot is not None:
+                self._free_slots.append(slot)
+        if old:
+            log.warning("dropped %d KV transfer reservations older than %.0f s", len(old), self.reserve_ttl)
+        return len(old)
+
     def reserve(self, hashes: list[int], page_bytes: int, peer: dict | None = None) -> dict:
         """``peer``: what the producer said about itself (host_id, transport, gpu); a producer on
         this host with a GPU gets landing-window slots, as many pages as there are free slots."""
@@ -300,6 +323,8 @@ class KVReceiver:
         mine = pool.stride(0) * pool.element_size()
         if page_bytes != mine:
             raise ValueError(f"page size mismatch: sender {page_bytes}, receiver {mine}")
+        if self._reserved_at:
+            self._expire()
         missing = [h for h in hashes if not bm.contains(h) and h not in self.reserved]
         peer = peer or {}
         slots = None
@@ -319,8 +344,12 @@ class KVReceiver:
         if by_ipc:
             slots = [self._free_slots.pop() for _ in missing]
         pages = bm.allocate(len(missing)) if missing else []
+        import time
+
+        now = time.time()
         for i, (h, p) in enumerate(zip(missing, pages)):
             self.reserved[h] = p
+            self._reserved_at[h] = now
             if slots is not None:
                 self._slot_of[h] = slots[i]
         return {"pages": pages, "missing": missing, "more": more,
@@ -368,6 +397,8 @@ class KVReceiver:
         are returned either way."""
         bm = self.engine.bm
         pool = self.engine.runner.pool
+        if any(self.reserved.get(h) != p for h, p in zip(hashes, pages)):
+            raise ValueError("commit of pages that are not reserved (the reservation expired?)")
         slots = [self._slot_of.pop(h, None) for h in hashes]
         if landed:
             if any(s is None for s in slots):
@@ -385,6 +416,7 @@ class KVReceiver:
         self._free_slots.extend(s for s in slots if s is not None)
         for h, p in zip(hashes, pages):
             self.reserved.pop(h, None)
+            self._reserved_at.pop(h, None)
             bm.register(p, h)
         bm.free(pages)  # published pages wait in the prefix cache (evictable, LRU)
         return {"ok": True, "published": len(pages)}
