@@ -28,6 +28,7 @@ from .discovery import create_service_discovery
 from .feature_gates import get_feature_gates, initialize_feature_gates
 from .files import DEFAULT_USER, initialize_storage
 from .log import init_logger, set_level
+from .protocols import model_card, model_list
 from .proxy import (route_general_request, route_general_transcriptions,
                     route_sleep_wakeup_request)
 from .rewriter import get_request_rewriter
@@ -218,17 +219,13 @@ async def h_models(request):
                 continue
             seen.add(mid)
             info = ep.model_info.get(mid)
-            cards.append({"id": mid, "object": "model",
-                          "created": info.created if info else int(ep.added_timestamp),
-                          "owned_by": info.owned_by if info else "vllm",
-                          "root": info.root if info else None,
-                          "parent": info.parent if info else None})
+            cards.append(model_card(mid, info.created, info.owned_by, info.root, info.parent) if info
+                         else model_card(mid, ep.added_timestamp))
     aliases = getattr(state.service_discovery, "aliases", None) or {}
     for alias, target in aliases.items():
         if alias not in seen and target in seen:
-            cards.append({"id": alias, "object": "model", "created": int(state.start_time),
-                          "owned_by": "vllm", "root": target, "parent": None})
-    return web.json_response({"object": "list", "data": cards})
+            cards.append(model_card(alias, state.start_time, root=target))
+    return web.json_response(model_list(cards))
 
 
 async def h_engines(request):
