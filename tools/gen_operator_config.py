@@ -19,13 +19,32 @@ KINDS = {"vllmruntime": "vllmruntimes", "vllmrouter": "vllmrouters", "cacheserve
 LABELS = {"app.kubernetes.io/name": "vpsa-operator", "app.kubernetes.io/managed-by": "kustomize"}
 
 
+class _Compact(yaml.SafeDumper):
+    """Lists of plain scalars (verbs, apiGroups, resources, args) and small all-scalar maps
+    (labels, selectors) on one line; everything else in block style."""
+
+
+def _seq(dumper, data):
+    flat = all(isinstance(x, (str, int, float, bool)) for x in data)
+    return dumper.represent_sequence("tag:yaml.org,2002:seq", data, flow_style=flat)
+
+
+def _map(dumper, data):
+    flat = 0 < len(data) <= 3 and all(isinstance(v, (str, int, float, bool)) for v in data.values())
+    return dumper.represent_mapping("tag:yaml.org,2002:map", data.items(), flow_style=flat)
+
+
+_Compact.add_representer(list, _seq)
+_Compact.add_representer(dict, _map)
+
+
 def write(rel, *docs, header=None):
     path = os.path.join(OUT, rel)
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
         if header:
             f.write("".join(f"# {ln}\n" for ln in header.splitlines()))
-        f.write(yaml.safe_dump_all(docs, sort_keys=False))
+        f.write(yaml.dump_all(docs, Dumper=_Compact, sort_keys=False, width=110))
 
 
 def kustomization(rel, resources, **extra):
