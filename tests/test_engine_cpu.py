@@ -240,3 +240,15 @@ def test_kv_transfer_reservations_expire_when_the_producer_never_commits():
         recv.commit([11, 12, 13], res["pages"])
     recv.commit([21], again["pages"])
     assert eng.bm.contains(21) and not recv.reserved and not recv._reserved_at
+
+
+def test_ipc_safe_size_avoids_the_sizes_hipipc_cannot_map():
+    from vllm_production_stack_amd.parallel.kv_transfer import ipc_safe_size
+
+    G = 1 << 30
+    for want in (G // 2, G, 4 * G, 4 * G + G // 2, 5 * G, 8 * G, 9 * G, 12 * G, 100 * G):
+        assert ipc_safe_size(want) == want  # measured to map
+    for want in (2 * G, 2 * G + G // 2, 3 * G, 6 * G, 7 * G, 10 * G, 14 * G, 4 * G - 1):
+        got = ipc_safe_size(want)
+        assert got <= want and want - got <= 2 * G + (2 << 20) and (got & 0xFFFFFFFF) < 0x80000000 and got % 4096 == 0
+    assert ipc_safe_size(2 * G) == 2 * G - (2 << 20)

@@ -4,14 +4,13 @@ Protocol (control plane = the replicas' own HTTP ports, data plane chosen per pa
   1. producer  POST <decode>/kv/reserve {hashes}      -> {pages, missing, transports...}
      the decode replica allocates HBM pages for the hashes it does not hold yet;
   2. producer  moves the page bytes:
-        ipc   the decode replica's LANDING WINDOW (a device allocation of its own, a power of
-              two in size: LMCACHE_NIXL_BUFFER_SIZE, default 1 GiB) is mapped through a hipIpc handle and written with
+        ipc   the decode replica's LANDING WINDOW (a device allocation of its own, of a size
+              hipIpc can map: LMCACHE_NIXL_BUFFER_SIZE, default 1 GiB, see ipc_safe_size) is mapped through a hipIpc handle and written with
               hipMemcpyAsync on a side stream (SDMA over the direct xGMI link); at commit the
               decode replica copies window slots into its pool pages on the device.  The pool
-              itself is not exported: hipIpcOpenMemHandle was measured to never return for
-              some allocation sizes (6, 7 and 7.03 GiB hang; 4.5, 5, 8, 12, 16, 64, 100 GiB
-              map in under a millisecond; benchmarks/ipc_probe.py), and a pool's size follows
-              from the memory budget.  A request with more pages than free slots goes in
+              itself is not exported: hipIpcOpenMemHandle never returns for allocations
+              whose size modulo 4 GiB is 2 GiB or more (benchmarks/ipc_probe.py), and a pool's
+              size follows from the memory budget.  A request with more pages than free slots goes in
               rounds (reserve -> push -> commit, repeated),
         rccl  ncclSend / ncclRecv of whole pages on side streams, over a two-rank RCCL
               communicator created per (prefill, decode) pair (the unique id travels over the
@@ -111,6 +110,17 @@ def _post(url: str, payload: dict, raw: bytes | None = None, timeout: float = 60
     with urllib.request.urlopen(req, timeout=timeout) as r:
         body = r.read()
     return json.loads(body) if body else {}
+
+
+def ipc_safe_size(nbytes: int) -> int:
+    """Largest size <= ``nbytes`` (whole 4 KiB pages) that hipIpcOpenMemHandle maps.  Measured on
+    ROCm 7.2 / MI355X: the importer never returns when the allocation's size modulo 4 GiB is
+    2 GiB or more (2, 2.5, 3, 6, 7, 10, 14 GiB hang; 0.5, 1, 4, 4.5, 5, 8, 9, 12, 16, 64, 100 GiB
+    map in under a millisecond), as if the size went through a signed 32-bit value somewhere."""
+    nbytes = max(int(nbytes), 0) & ~4095
+    if nbytes & 0x80000000:
+        nbytes = (nbytes & ~0xFFFFFFFF) | (0x80000000 - (2 << 20))
+    return nbytes
 
 
 def export_ipc_handle(pool: torch.Tensor) -> tuple[str, int] | None:
@@ -282,7 +292,7 @@ class KVReceiver:
             want = getattr(getattr(self.engine.cfg, "kv_offload", None), "pd_buffer_bytes", 1 << 30)
             if os.environ.get("VPSA_PD_LANDING_MIB"):
                 want = int(os.environ["VPSA_PD_LANDING_MIB"]) << 20
-            nbytes = 1 << max(int(want), 1).bit_length() - 1  # largest power of two that fits
+            nbytes = ipc_safe_size(int(want))
             lib = comm()
             ptr = lib.comm_dev_alloc(c_size_t(nbytes)) if nbytes >= page_bytes else None
             if ptr:
