@@ -285,7 +285,10 @@ API void* comm_ar_create(int rank, int world, size_t max_bytes) {
   const size_t total = sizeof(ArShared) + 2 * max_bytes;
   // hipIpcOpenMemHandle never returns for an allocation whose size modulo 4 GiB is 2 GiB or more
   // (measured, ROCm 7.2): refuse such a buffer here rather than hang the peers in comm_ar_open.
-  if ((total & 0xFFFFFFFFull) >= 0x80000000ull) return nullptr;
+  if ((total & 0xFFFFFFFFull) >= 0x80000000ull) {
+    delete c;
+    return nullptr;
+  }
   if (hipMalloc((void**)&c->local, total) != hipSuccess) {
     delete c;
     return nullptr;
