@@ -59,14 +59,16 @@ def main():
     ap.add_argument("--max-tokens", type=int, default=16)
     ap.add_argument("--pages", type=int, default=0)
     ap.add_argument("--gpus-per-node", type=int, default=1, help="> 1: engine i takes GPU i modulo this")
+    ap.add_argument("--model", default="", help="default: llama-3-8b (tiny-llama with --small)")
     ap.add_argument("--small", action="store_true", help="tiny CPU model (plumbing rehearsal, pages go by TCP)")
     ap.add_argument("--base-port", type=int, default=18900)
     ap.add_argument("--request-timeout", type=float, default=90.0)
     ap.add_argument("--prefill-first", action="store_true", help="start the prefill replicas before the decode ones")
     a = ap.parse_args()
-    model = "tiny-llama" if a.small else "llama-3-8b"
-    n_tok = a.prompt_tokens or (500 if a.small else 6000)
-    pages = a.pages or (64 if a.small else 900)
+    model = a.model or ("tiny-llama" if a.small else "llama-3-8b")
+    tiny = model.startswith("tiny")
+    n_tok = a.prompt_tokens or (500 if tiny else 6000)
+    pages = a.pages or (64 if tiny else 900)
     log_dir = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "/tmp"
     engines = [(f"prefill-{i}", "prefill", a.base_port + 1 + i) for i in range(a.prefill)] + \
               [(f"decode-{i}", "decode", a.base_port + 1 + a.prefill + i) for i in range(a.decode)]
@@ -90,7 +92,7 @@ def main():
             if a.gpus_per_node > 1:
                 env["HIP_VISIBLE_DEVICES"] = str(i % a.gpus_per_node)
             cmd = [sys.executable, "-m", "vllm_production_stack_amd.engine.cli", "serve", model, "--host", "127.0.0.1",
-                   "--port", str(port), "--max-model-len", "4096" if a.small else "32000", "--enable-prefix-caching",
+                   "--port", str(port), "--max-model-len", "4096" if tiny else "32000", "--enable-prefix-caching",
                    "--num-gpu-blocks-override", str(pages), "--max-num-seqs", "32", "--log-level", "info",
                    "--kv-transfer-config", json.dumps({"kv_connector": "LMCacheConnectorV1",
                                                        "kv_role": "kv_producer" if role == "prefill" else "kv_consumer"})]
