@@ -176,7 +176,8 @@ def test_remote_cache_shared_between_engines(serde):
         loop.call_soon_threadsafe(loop.stop)
 
 
-def test_controller_reporting_and_pd_push():
+@pytest.mark.parametrize("api_key", [None, "sekret"])
+def test_controller_reporting_and_pd_push(api_key):
     from vllm_production_stack_amd.controller import KVController, start_controller
     from vllm_production_stack_amd.engine.async_engine import AsyncLLMEngine
     from vllm_production_stack_amd.engine.block_manager import chain_hashes
@@ -188,7 +189,7 @@ def test_controller_reporting_and_pd_push():
 
     async def go():
         dec_cfg = EngineConfig(model="tiny-llama", device="cpu", dtype="float32", max_model_len=1024,
-                               num_gpu_blocks_override=32, host="127.0.0.1",
+                               num_gpu_blocks_override=32, host="127.0.0.1", api_key=api_key,
                                kv_transfer=KVTransferConfig("LMCacheConnectorV1", "kv_consumer"))
         dec = LLMEngine(dec_cfg)
         dae = AsyncLLMEngine(dec)
@@ -196,7 +197,7 @@ def test_controller_reporting_and_pd_push():
         drunner = await serve(dae, "127.0.0.1", 0)
         dport = drunner.addresses[0][1]
         pre_cfg = EngineConfig(model="tiny-llama", device="cpu", dtype="float32", max_model_len=1024,
-                               num_gpu_blocks_override=32, host="127.0.0.1", port=1,
+                               num_gpu_blocks_override=32, host="127.0.0.1", port=1, api_key=api_key,
                                kv_transfer=KVTransferConfig("LMCacheConnectorV1", "kv_producer"),
                                kv_offload=KVOffloadConfig(enable_controller=True, instance_id="prefill-0",
                                                           controller_url=f"127.0.0.1:{cport}"))

@@ -38,6 +38,7 @@ from .. import _native
 
 log = logging.getLogger("vpsa.kvxfer")
 _comm = None
+_api_key: str | None = None  # bearer token of the deployment's replicas (they share VLLM_API_KEY)
 _peer_maps: dict[tuple[str, str], int] = {}  # (target url, handle) -> mapped base of its landing window
 _rccl_peers: dict[str, tuple[int, str]] = {}  # target url -> (communicator, key on the decode side)
 
@@ -106,6 +107,8 @@ def _post(url: str, payload: dict, raw: bytes | None = None, timeout: float = 60
         meta = json.dumps(payload).encode()
         data = len(meta).to_bytes(4, "little") + meta + raw
         headers = {"Content-Type": "application/octet-stream"}
+    if _api_key:
+        headers["Authorization"] = f"Bearer {_api_key}"
     req = urllib.request.Request(url, data=data, headers=headers)
     with urllib.request.urlopen(req, timeout=timeout) as r:
         body = r.read()
@@ -143,7 +146,14 @@ def export_ipc_handle(pool: torch.Tensor) -> tuple[str, int] | None:
 
 
 def push_request_pages(engine, target: str, hashes: list[int], pages: list[int]) -> str:
-    """Producer side: make ``hashes`` resident on the decode replica at ``target``."""
+    """Producer side: make ``hashes`` resident on the decode replica at ``target``.  The calls carry
+    this replica's API key: the replicas of one deployment are started with the same VLLM_API_KEY
+    (/root/reference/helm/templates/deployment-vllm-multi.yaml:216-230), and the decode replica's
+    /kv/* endpoints sit behind the same bearer check as its OpenAI endpoints."""
+    import os
+
+    global _api_key
+    _api_key = getattr(engine.cfg, "api_key", None) or os.environ.get("VLLM_API_KEY") or None
     runner = engine.runner
     pool = runner.pool
     page_bytes = pool.stride(0) * pool.element_size()
