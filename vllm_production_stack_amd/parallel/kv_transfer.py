@@ -127,9 +127,11 @@ def ipc_safe_size(nbytes: int) -> int:
 
 
 def export_ipc_handle(pool: torch.Tensor) -> tuple[str, int] | None:
-    """(hex hipIpc handle of the device allocation that contains the KV pool, byte offset of the
-    pool inside that allocation).  The caching allocator may place the pool in the middle of a
-    larger block; the peer maps the whole block and adds the offset."""
+    """(hex hipIpc handle of the device allocation that contains the tensor, byte offset of the
+    tensor inside that allocation).  The caching allocator may place a tensor in the middle of a
+    larger block; a peer maps the whole block and adds the offset.  Whether the peer can map it
+    depends on the BLOCK's size (see ``ipc_safe_size``), which is why the P/D data plane exports
+    a window it allocated itself; this function serves benchmarks/ipc_probe.py."""
     if not pool.is_cuda:
         return None
     try:
