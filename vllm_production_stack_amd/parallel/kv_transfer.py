@@ -220,6 +220,8 @@ def _push_ipc(pool, target, handle_hex, offset, page_bytes, src_pages, dst_slots
         base = lib.comm_ipc_open(ctypes.create_string_buffer(h, len(h)))
         if not base:
             raise RuntimeError("hipIpcOpenMemHandle failed")
+        for key in [k for k in _peer_maps if k[0] == target]:  # the replica behind this URL restarted
+            lib.comm_ipc_close(c_void_p(_peer_maps.pop(key)))
         _peer_maps[(target, handle_hex)] = base
     n = len(src_pages)
     sp = (ctypes.c_int64 * n)(*src_pages)
