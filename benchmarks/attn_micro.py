@@ -62,13 +62,19 @@ def prefill_case(name: str, n_seqs: int, q_len: int, prefix: int, iters: int,
     out = torch.empty_like(q)
     cu = torch.arange(0, (n_seqs + 1) * q_len, q_len, dtype=torch.int32, device=DEV)
     ctxs = torch.full((n_seqs,), ctx, dtype=torch.int32, device=DEV)
-    ts, tq = ops.build_prefill_tiles([q_len] * n_seqs, N_Q, N_KV)
-    ts = torch.tensor(ts, dtype=torch.int32, device=DEV)
-    tq = torch.tensor(tq, dtype=torch.int32, device=DEV)
     scale = HD ** -0.5
+    tiles = {}
+    for v in variants:  # the work list depends on the kernel's tile height
+        ops.set_prefill_variant(v)
+        rows = ops.prefill_tile_rows([q_len] * n_seqs, N_Q, N_KV)
+        ts, tq = ops.build_prefill_tiles([q_len] * n_seqs, N_Q, N_KV, rows)
+        tiles[v] = (torch.tensor(ts, dtype=torch.int32, device=DEV),
+                    torch.tensor(tq, dtype=torch.int32, device=DEV), rows)
+    cur = {"v": variants[0]}
 
     def run():
-        ops.paged_prefill(q, out, pool, 0, bt, cu, ctxs, ts, tq, N_Q, N_KV, HD, scale)
+        ts, tq, rows = tiles[cur["v"]]
+        ops.paged_prefill(q, out, pool, 0, bt, cu, ctxs, ts, tq, N_Q, N_KV, HD, scale, rows)
 
     keys = sum(prefix + i + 1 for i in range(q_len)) * n_seqs  # causal (query, key) pairs
     flops = 4.0 * keys * HD * N_Q
@@ -78,6 +84,7 @@ def prefill_case(name: str, n_seqs: int, q_len: int, prefix: int, iters: int,
     for _ in range(3):
         for v in variants:
             ops.set_prefill_variant(v)
+            cur["v"] = v
             samples[v].append(timed(run, iters))
     for v in variants:
         ms = sorted(samples[v])[1]
@@ -120,7 +127,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--cases", default="prefill_cold,prefill_warm,decode")
-    ap.add_argument("--variants", default="0,1,2,3,-1", help="prefill kernels to time (-1 = automatic choice)")
+    ap.add_argument("--variants", default="2,3,4,5,6,7,-1", help="prefill kernels to time (-1 = automatic choice)")
     a = ap.parse_args()
     cases = a.cases.split(",")
     variants = tuple(int(v) for v in a.variants.split(","))
@@ -130,6 +137,8 @@ def main():
         print(json.dumps(prefill_case("prefill_first", 1, 8192, 0, a.iters, variants)), flush=True)
     if "prefill_last" in cases:  # last chunk of a 21k-token prompt
         print(json.dumps(prefill_case("prefill_last", 1, 4616, 16384, a.iters, variants)), flush=True)
+    if "prefill_bulk" in cases:  # enough workgroups that the tail of the launch does not matter
+        print(json.dumps(prefill_case("prefill_bulk", 8, 4096, 8192, a.iters, variants)), flush=True)
     if "prefill_warm" in cases:
         print(json.dumps(prefill_case("prefill_warm", 40, 128, 21000, a.iters, variants)), flush=True)
     if "decode" in cases:

@@ -23,6 +23,7 @@
 // the whole group.  Context is split across the 4 waves of a workgroup and across
 // `num_splits` workgroups; a small second kernel merges the split partials.
 #include "common.h"
+#include <type_traits>
 
 #define NEG_BIG (-1.0e30f)
 
@@ -482,11 +483,523 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel_v2(
   }
 }
 
-// Kernel selection for in-process A/B timing (0 = first generation, 1 = second generation,
-// 2 = second generation with raised wave priority around the MFMA clusters).
-// -1 = automatic (generation 2; head-major tile order when sequences have many q-tiles);
+// ---------------------------------------------------------------------------------
+// Third-generation prefill kernel: ONE wave per SIMD with the whole 512-register file,
+// 64 query rows per wave.
+//   * a workgroup is still 4 waves = the 4 query heads of one GQA group against one KV head's
+//     K/V stream, but every wave now owns TWO 32-row query blocks: each K / V^T fragment read
+//     from LDS feeds two MFMAs (one per block), so LDS reads, LDS writes, L2 reads and barriers
+//     per MFMA are all halved against the second generation;
+//   * the unit of the online softmax is a 32-key half tile, software-pipelined one deep: while
+//     the probabilities of half tile u are exponentiated (VALU) the scores of half tile u+1 are
+//     already being computed (16 MFMAs), and the row maxima of u+1 are taken under the 16 PV
+//     MFMAs of u.  Two score sets of 32 registers alternate, so nothing is copied;
+//   * three 32 KiB LDS buffers in a ring (tile t multiplied into O, tile t+1 read for the next
+//     scores, tile t+2 being written): one barrier per 64-key tile;
+//   * tiles below the diagonal of the whole 64-row block take a mask-free body; the at most
+//     two tiles that cross it take a second body with the causal mask;
+//   * lazy rescale (LAZY_THR) as in the second generation.
+// grid = (num_tiles of 64 rows, n_kv * G / 4); block = 256; dynamic LDS = 96 KiB.
+// ---------------------------------------------------------------------------------
+// O accumulators of the third-generation prefill kernel live in the accumulator half of the
+// register file for the whole kernel: the MFMA is written as inline asm with "a" constraints so
+// the compiler cannot place them in (or copy them through) arch VGPRs.  The compiler does not
+// pad hazards of an asm statement, so the two wait states between a vector write of an operand
+// (packed probabilities) and the MFMA that reads it are inside the string.
+__device__ __forceinline__ void mfma_acc_agpr(f32x16& acc, bf16x8 a, bf16x8 b) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+// Score MFMAs of the hand-interleaved stream: destination in arch VGPRs (the softmax reads it),
+// query fragments from AGPRs (loaded once per workgroup).  The first MFMA of a chain takes the
+// constant 0 as its accumulator input.  Whoever reads the result with vector instructions must be
+// at least one full MFMA (12 wait states) behind the last MFMA of the chain: in the stream below
+// the first reader is eight MFMAs later.
+__device__ __forceinline__ void mfma_s_first(f32x16& d, bf16x8 a, bf16x8 b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma_s_next(f32x16& d, bf16x8 a, bf16x8 b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+}
+// Values produced by an asm MFMA are not known to the compiler's hazard recogniser: before vector
+// code reads them (rescale, epilogue) let the matrix pipe drain.
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+// Keeps a value (and the instruction that made it) where the source put it.
+#define VPSA_PIN(x) asm volatile("" : "+v"(x))
+
+template <bool HEAD_MAJOR, int SCHED>
+__global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v3(
+    const uint16_t* __restrict__ q, long q_stride, uint16_t* __restrict__ out, long out_stride,
+    const uint16_t* __restrict__ cache, long page_stride, long v_offset,
+    const int* __restrict__ block_tables, int max_blocks, const int* __restrict__ cu_q,
+    const int* __restrict__ ctx_lens, const int* __restrict__ tile_seq,
+    const int* __restrict__ tile_q0, int n_q, int n_kv, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // 3 x (16 KiB K + 16 KiB V)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31;
+  const int h = lane >> 5;
+
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (HEAD_MAJOR) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    by = lin % gridDim.y;
+    bx = lin / gridDim.y;
+  }
+  const int G = n_q / n_kv;
+  const int groups_per_kv = G >> 2;
+  const int kvh = by / groups_per_kv;
+  const int head = kvh * G + (by % groups_per_kv) * 4 + wave;
+
+  const int seq = tile_seq[bx];
+  const int q0 = tile_q0[bx];
+  const int row0 = cu_q[seq];
+  const int q_len = cu_q[seq + 1] - row0;
+  const int ctx = ctx_lens[seq];
+  const int pos0 = ctx - q_len;
+
+  int my_row[2], my_pos[2];
+  bool row_ok[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    my_row[rb] = q0 + 32 * rb + r;
+    row_ok[rb] = my_row[rb] < q_len;
+    my_pos[rb] = row_ok[rb] ? pos0 + my_row[rb] : ctx - 1;
+  }
+  int b_last = q0 + 63;
+  if (b_last > q_len - 1) b_last = q_len - 1;
+  const int n_tiles = (pos0 + b_last) / PAGE + 1;
+  const int last = n_tiles - 1;
+  // tiles [0, n_full) lie entirely at or below the first row's position: no mask for any row
+  const int n_full = (pos0 + q0 + 1) / PAGE;
+
+  bf16x8 qf[2][8];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const uint16_t* qp =
+        q + (long)(row0 + (row_ok[rb] ? my_row[rb] : 0)) * q_stride + head * HEAD_DIM + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + 16 * ks);
+      if (!row_ok[rb]) v = (u32x4){0, 0, 0, 0};
+      qf[rb][ks] = __builtin_bit_cast(bf16x8, v);
+      // from here on the fragment is an AGPR value: every MFMA of the main loop reads it there
+      if (SCHED == 1) asm volatile("" : "+a"(qf[rb][ks]));
+    }
+  }
+
+  const int* bt = block_tables + (long)seq * max_blocks;
+  const long kv_head_off = (long)kvh * PAGE * HEAD_DIM;
+
+  u32x4 sk[4], sv[4];
+  auto stage_load = [&](int tile) {
+    const long page = bt[tile];
+    const uint16_t* kp = cache + page * page_stride + kv_head_off + tid * 8;
+    const uint16_t* vp = kp + v_offset;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sk[i] = *reinterpret_cast<const u32x4*>(kp + i * 2048);
+      sv[i] = *reinterpret_cast<const u32x4*>(vp + i * 2048);
+    }
+  };
+  int wk_off[4], wv_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = i * 256 + tid;
+    const int key = id >> 4, c = id & 15;
+    wk_off[i] = key * 256 + ((c ^ (key & 15)) << 4);
+    const int d = id >> 3, cv = id & 7;
+    wv_off[i] = 16384 + d * 128 + ((cv ^ ((d >> 1) & 7)) << 4);
+  }
+  auto stage_write = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4*>(buf + wk_off[i]) = sk[i];
+      *reinterpret_cast<u32x4*>(buf + wv_off[i]) = sv[i];
+    }
+  };
+
+  f32x16 o_acc[2][4];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o_acc[rb][dt][i] = 0.f;
+  float m_run[2] = {NEG_BIG, NEG_BIG};
+  float l_run[2] = {0.f, 0.f};
+
+  const int krow = (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1);
+  const int k_sw = krow & 15;
+  const int k_row_off = krow * 256;
+  // V^T read offsets of this lane for the four channel blocks
+  int v_row_off[4], v_sw[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const int d = 32 * dt + r;
+    v_row_off[dt] = 16384 + d * 128;
+    v_sw[dt] = (d >> 1) & 7;
+  }
+
+  // S^T of the 32-key half `tt` of the tile in `buf`, both row blocks
+  auto qk_half = [&](const char* buf, int tt, f32x16 (&s)[2]) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      s[0][i] = 0.f;
+      s[1][i] = 0.f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      bf16x8 a = lds_read_frag(buf, tt * 8192 + k_row_off + (((2 * ks + h) ^ k_sw) << 4));
+      s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0][ks], s[0], 0, 0, 0);
+      s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[1][ks], s[1], 0, 0, 0);
+    }
+  };
+  // accumulator reg i of lane half h = key kbase + 32 tt + 16 (i>>3) + 8 h + (i&7)
+  auto mask_half = [&](int tile, int tt, f32x16 (&s)[2]) {
+    const int kb = tile * PAGE + 32 * tt + 8 * h;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (kb + 16 * (i >> 3) + (i & 7) > my_pos[rb]) s[rb][i] = NEG_BIG;
+  };
+  auto max_half = [&](const f32x16 (&s)[2], float (&mt)[2]) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      float mx0 = fmaxf(s[rb][0], s[rb][1]);
+      float mx1 = fmaxf(s[rb][2], s[rb][3]);
+#pragma unroll
+      for (int i = 4; i < 16; i += 4) {
+        mx0 = fmaxf(fmaxf(mx0, s[rb][i]), s[rb][i + 1]);
+        mx1 = fmaxf(fmaxf(mx1, s[rb][i + 2]), s[rb][i + 3]);
+      }
+      float mx = fmaxf(mx0, mx1);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mt[rb] = fmaxf(mx * scale_log2e, NEG_BIG);
+    }
+  };
+  auto rescale = [&](const float (&mt)[2]) {
+    const bool grow = (mt[0] > m_run[0] + LAZY_THR) || (mt[1] > m_run[1] + LAZY_THR);
+    if (__any(grow)) {
+      mfma_drain();
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const float m_new = fmaxf(m_run[rb], mt[rb]);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_new);
+        m_run[rb] = m_new;
+        l_run[rb] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o_acc[rb][dt][i] *= alpha;
+      }
+    }
+  };
+  auto exp_half = [&](const f32x16 (&s)[2], bf16x8 (&pf)[2][2]) {
+#pragma unroll
+    for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const float nm = -m_run[rb];
+        float ps0 = 0.f, ps1 = 0.f;
+        u32x4 pk;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const float p0 =
+              __builtin_amdgcn_exp2f(__builtin_fmaf(s[rb][8 * sh + 2 * jj], scale_log2e, nm));
+          const float p1 =
+              __builtin_amdgcn_exp2f(__builtin_fmaf(s[rb][8 * sh + 2 * jj + 1], scale_log2e, nm));
+          ps0 += p0;
+          ps1 += p1;
+          pk[jj] = pack_bf16x2(p0, p1);
+        }
+        pf[rb][sh] = __builtin_bit_cast(bf16x8, pk);
+        l_run[rb] += ps0 + ps1;
+      }
+  };
+  // O^T += V^T(keys of half tt) . P^T, 16-key slice `sh` first for all channels, then the next
+  auto pv_half = [&](const char* buf, int tt, const bf16x8 (&pf)[2][2]) {
+#pragma unroll
+    for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x8 a = lds_read_frag(buf, v_row_off[dt] + (((4 * tt + 2 * sh + h) ^ v_sw[dt]) << 4));
+        mfma_acc_agpr(o_acc[0][dt], a, pf[0][sh]);
+        mfma_acc_agpr(o_acc[1][dt], a, pf[1][sh]);
+      }
+  };
+
+  // One half-tile step with the instruction stream interleaved by hand (SCHED = 1): 32 MFMAs,
+  // each followed by the slice of vector work that fits in its shadow, and a scheduling fence
+  // so that the compiler keeps the slices where they are.
+  //   MFMAs  0-15: scores of the NEXT half tile (kbuf, half ktt) -> sn
+  //   MFMAs 16-23: O += V^T(keys 0-15 of the current half) . P,  24-31: keys 16-31
+  //   vector work: the 32 exponentials of the current scores `sc` (24 under the score MFMAs,
+  //   8 under the first PV MFMAs); under the last 8 MFMAs the row maxima of `sn` and one
+  //   staging operation per MFMA (STAGE 1: the 8 LDS writes of the tile held in the staging
+  //   registers, STAGE 2: the 8 global loads of the tile after it).
+  // LDS fragments are read two MFMA pairs ahead into four rotating registers `fr`; the last two
+  // pairs fetch the first two K fragments of the following step (nkbuf, half nktt), so a step
+  // starts with its operands already on the way.
+  bf16x8 fr[4];
+  const uint16_t* ld_kp = nullptr;  // source of the tile being loaded (STAGE 2)
+  auto fused_half = [&](auto stage_tag, const char* kbuf, int ktt, const char* vbuf, int vtt,
+                        const char* nkbuf, int nktt, char* wbuf, const f32x16 (&sc)[2],
+                        f32x16 (&sn)[2], float (&mn)[2], bool mask_next, int next_tile) {
+    constexpr int STAGE = decltype(stage_tag)::value;
+    const float nm[2] = {-m_run[0], -m_run[1]};
+    float ps[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float pv[32];     // probabilities between their exp2 and their pack (a few live at a time)
+    u32x4 pw[2][2];   // packed probabilities [row block][16-key slice]
+    // value v of 32: slice sh = v >> 4, row block rb = (v >> 3) & 1, element i = 8 sh + (v & 7).
+    // `start` issues the fma + exp2, `finish` (one MFMA later, so the exp2 result is ready and
+    // no wait state is needed) adds it to the row sum and packs each completed pair.
+    auto start = [&](int v) {
+      const int sh = v >> 4, rb = (v >> 3) & 1, i = 8 * sh + (v & 7);
+      pv[v] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[rb][i], scale_log2e, nm[rb]));
+      VPSA_PIN(pv[v]);
+    };
+    auto finish = [&](int v) {
+      const int sh = v >> 4, rb = (v >> 3) & 1;
+      ps[rb][v & 1] += pv[v];
+      VPSA_PIN(ps[rb][v & 1]);
+      if (v & 1) {
+        uint32_t w = pack_bf16x2(pv[v - 1], pv[v]);
+        VPSA_PIN(w);
+        pw[rb][sh][(v & 7) >> 1] = w;
+      }
+    };
+    // LDS read of item n: 0-7 = K fragments of this step, 8-15 = V^T fragments (sh = (n-8) >> 2,
+    // dt = (n-8) & 3), 16-17 = K fragments 0-1 of the following step
+    auto fetch = [&](int n) {
+      if (n < 8)
+        fr[n & 3] = lds_read_frag(kbuf, ktt * 8192 + k_row_off + (((2 * n + h) ^ k_sw) << 4));
+      else if (n < 16)
+        fr[n & 3] = lds_read_frag(
+            vbuf, v_row_off[(n - 8) & 3] + (((4 * vtt + 2 * ((n - 8) >> 2) + h) ^ v_sw[(n - 8) & 3]) << 4));
+      else
+        fr[n & 3] = lds_read_frag(nkbuf, nktt * 8192 + k_row_off + (((2 * (n - 16) + h) ^ k_sw) << 4));
+    };
+    auto stage_op = [&](int i) {  // i = 0..7
+      if (STAGE == 1) {
+        if (i < 4)
+          *reinterpret_cast<u32x4*>(wbuf + wk_off[i]) = sk[i];
+        else
+          *reinterpret_cast<u32x4*>(wbuf + wv_off[i - 4]) = sv[i - 4];
+      } else if (STAGE == 2) {
+        if (i < 4)
+          sk[i] = *reinterpret_cast<const u32x4*>(ld_kp + i * 2048);
+        else
+          sv[i - 4] = *reinterpret_cast<const u32x4*>(ld_kp + v_offset + (i - 4) * 2048);
+      }
+    };
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks == 0)
+        mfma_s_first(sn[0], fr[0], qf[0][0]);
+      else
+        mfma_s_next(sn[0], fr[ks & 3], qf[0][ks]);
+      fetch(ks + 2);
+      if (ks > 0) {
+        finish(3 * ks - 2);
+        finish(3 * ks - 1);
+      }
+      start(3 * ks);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks == 0)
+        mfma_s_first(sn[1], fr[0], qf[1][0]);
+      else
+        mfma_s_next(sn[1], fr[ks & 3], qf[1][ks]);
+      finish(3 * ks);
+      start(3 * ks + 1);
+      start(3 * ks + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float mx[2][2];
+    float mfin[2];
+#pragma unroll
+    for (int sh = 0; sh < 2; ++sh) {
+      if (sh == 1 && mask_next) mask_half(next_tile, ktt, sn);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int n = 8 + 4 * sh + dt;
+        const int g = 2 * (4 * sh + dt);  // PV MFMA index 0..15 of this and the next MFMA
+        mfma_acc_agpr(o_acc[0][dt], fr[n & 3], __builtin_bit_cast(bf16x8, pw[0][sh]));
+        fetch(n + 2);
+        if (sh == 0) {
+          if (dt == 0) finish(22);
+          finish(23 + 2 * dt);
+          start(24 + 2 * dt);
+        } else {
+          if (dt == 0) finish(31);
+          stage_op(2 * dt);
+        }
+        if (sh == 1) {
+          // row maxima of sn: block 0 under PV MFMAs 8-10, block 1 under 11-13, two chains each
+#define VPSA_MAX_SLICE(gg)                                                                 \
+  {                                                                                        \
+    const int rb_ = (gg) >= 11 ? 1 : 0, st_ = ((gg) - 8) % 3;                               \
+    if ((gg) >= 8 && (gg) <= 13) {                                                         \
+      if (st_ == 0) {                                                                      \
+        mx[rb_][0] = fmaxf(fmaxf(sn[rb_][0], sn[rb_][1]), sn[rb_][2]);                    \
+        mx[rb_][1] = fmaxf(fmaxf(sn[rb_][3], sn[rb_][4]), sn[rb_][5]);                    \
+      } else if (st_ == 1) {                                                               \
+        mx[rb_][0] = fmaxf(fmaxf(mx[rb_][0], sn[rb_][6]), sn[rb_][7]);                    \
+        mx[rb_][1] = fmaxf(fmaxf(mx[rb_][1], sn[rb_][8]), sn[rb_][9]);                    \
+        mx[rb_][0] = fmaxf(fmaxf(mx[rb_][0], sn[rb_][10]), sn[rb_][11]);                  \
+      } else {                                                                             \
+        mx[rb_][1] = fmaxf(fmaxf(mx[rb_][1], sn[rb_][12]), sn[rb_][13]);                  \
+        mx[rb_][0] = fmaxf(fmaxf(mx[rb_][0], sn[rb_][14]), sn[rb_][15]);                  \
+        mx[rb_][0] = fmaxf(mx[rb_][0], mx[rb_][1]);                                        \
+      }                                                                                    \
+      VPSA_PIN(mx[rb_][0]);                                                                \
+      VPSA_PIN(mx[rb_][1]);                                                                \
+    } else if ((gg) >= 14) { /* cross-half maximum and scaling of block gg - 14 */          \
+      const int rb2_ = (gg) - 14;                                                          \
+      const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx[rb2_][0]),      \
+                                                        __float_as_uint(mx[rb2_][0]), false, false); \
+      mfin[rb2_] = fmaxf(fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1])) * scale_log2e, NEG_BIG); \
+      l_run[rb2_] += ps[rb2_][0] + ps[rb2_][1];                                            \
+      VPSA_PIN(mfin[rb2_]);                                                                \
+    }                                                                                      \
+  }
+          VPSA_MAX_SLICE(g)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_acc_agpr(o_acc[1][dt], fr[n & 3], __builtin_bit_cast(bf16x8, pw[1][sh]));
+        if (sh == 0) {
+          finish(24 + 2 * dt);
+          start(24 + 2 * dt + 1);
+        } else {
+          stage_op(2 * dt + 1);
+          VPSA_MAX_SLICE(g + 1)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#undef VPSA_MAX_SLICE
+    mn[0] = mfin[0];
+    mn[1] = mfin[1];
+  };
+
+  // ring state: byte offsets of the buffers holding tile t, tile t+1, and the one to fill
+  int b_cur = 0, b_nxt = 32768, b_wr = 65536;
+
+  stage_load(0);
+  stage_write(lds);
+  stage_load(last < 1 ? last : 1);
+  stage_write(lds + 32768);
+  stage_load(last < 2 ? last : 2);
+  __syncthreads();
+
+  f32x16 sA[2], sB[2];
+  float mA[2], mB[2];
+  qk_half(lds, 0, sA);
+  if (n_full < 1) mask_half(0, 0, sA);
+  max_half(sA, mA);
+
+  // One 64-key tile = two half-tile steps.  Entering: sA / mA = scores and row maxima of
+  // (tile t, half 0).  Leaving: sA / mA = those of (tile t+1, half 0).
+#define VPSA_V3_TILE(t, MASKED)                                                       \
+  {                                                                                   \
+    if (SCHED == 1) {                                                                 \
+      {                                                                               \
+        const int nt = (t) + 3;                                                       \
+        const long page = bt[nt < last ? nt : last];                                  \
+        ld_kp = cache + page * page_stride + kv_head_off + tid * 8;                   \
+      }                                                                               \
+      rescale(mA);                                                                    \
+      fused_half(std::integral_constant<int, 1>{}, lds + b_cur, 1, lds + b_cur, 0, lds + b_nxt, 0, \
+                 lds + b_wr, sA, sB, mB, MASKED && (t) >= n_full, (t));               \
+      rescale(mB);                                                                    \
+      fused_half(std::integral_constant<int, 2>{}, lds + b_nxt, 0, lds + b_cur, 1, lds + b_nxt, 1, \
+                 lds + b_wr, sB, sA, mA, MASKED && (t) + 1 >= n_full, (t) + 1);       \
+    } else {                                                                          \
+      stage_write(lds + b_wr);                                                        \
+      {                                                                               \
+        const int nt = (t) + 3;                                                       \
+        stage_load(nt < last ? nt : last);                                            \
+      }                                                                               \
+      rescale(mA);                                                                    \
+      {                                                                               \
+        bf16x8 pf[2][2];                                                              \
+        exp_half(sA, pf);                                                             \
+        qk_half(lds + b_cur, 1, sB);                                                  \
+        pv_half(lds + b_cur, 0, pf);                                                  \
+        if (MASKED && (t) >= n_full) mask_half((t), 1, sB);                           \
+        max_half(sB, mB);                                                             \
+      }                                                                               \
+      rescale(mB);                                                                    \
+      {                                                                               \
+        bf16x8 pf[2][2];                                                              \
+        exp_half(sB, pf);                                                             \
+        qk_half(lds + b_nxt, 0, sA);                                                  \
+        pv_half(lds + b_cur, 1, pf);                                                  \
+        if (MASKED && (t) + 1 >= n_full) mask_half((t) + 1, 0, sA);                   \
+        max_half(sA, mA);                                                             \
+      }                                                                               \
+    }                                                                                 \
+    __syncthreads();                                                                  \
+    const int tmp = b_cur;                                                            \
+    b_cur = b_nxt;                                                                    \
+    b_nxt = b_wr;                                                                     \
+    b_wr = tmp;                                                                       \
+  }
+
+  // operands of the first hand-interleaved step: K fragments 0-1 of (tile 0, half 1)
+  if (SCHED == 1) {
+    fr[0] = lds_read_frag(lds, 8192 + k_row_off + (((0 + h) ^ k_sw) << 4));
+    fr[1] = lds_read_frag(lds, 8192 + k_row_off + (((2 + h) ^ k_sw) << 4));
+  }
+
+  int t = 0;
+  // mask-free iterations: neither tile t nor tile t+1 crosses the diagonal
+  const int n_fast = n_full - 1 < last ? n_full - 1 : last;
+  for (; t < n_fast; ++t) VPSA_V3_TILE(t, false)
+  for (; t < last; ++t) VPSA_V3_TILE(t, true)
+#undef VPSA_V3_TILE
+  // last tile: nothing left to prefetch after its second half
+  {
+    rescale(mA);
+    bf16x8 pf[2][2];
+    exp_half(sA, pf);
+    qk_half(lds + b_cur, 1, sB);
+    pv_half(lds + b_cur, 0, pf);
+    if (last >= n_full) mask_half(last, 1, sB);
+    max_half(sB, mB);
+    rescale(mB);
+    exp_half(sB, pf);
+    pv_half(lds + b_cur, 1, pf);
+  }
+
+  mfma_drain();
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const float l_tot = l_run[rb] + __shfl_xor(l_run[rb], 32, 64);
+    if (row_ok[rb]) {
+      const float inv = 1.f / l_tot;
+      uint16_t* op = out + (long)(row0 + my_row[rb]) * out_stride + head * HEAD_DIM;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          u32x2 w;
+          w[0] = pack_bf16x2(o_acc[rb][dt][4 * g4] * inv, o_acc[rb][dt][4 * g4 + 1] * inv);
+          w[1] = pack_bf16x2(o_acc[rb][dt][4 * g4 + 2] * inv, o_acc[rb][dt][4 * g4 + 3] * inv);
+          *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g4 + 4 * h) = w;
+        }
+    }
+  }
+}
+
+// Kernel selection.  -1 = automatic: the kernel follows the tile height the host built its work
+// list for (64 rows: third generation; 32 * (4 / GP) rows: second generation), head-major tile
+// order when sequences have many q-tiles.  Fixed choices are for A/B timing and tests:
 // 0 = first generation, 1 = generation 2 without wave priorities, 2 = generation 2,
-// 3 = generation 2 with head-major tile order  (fixed choices are for A/B timing and tests)
+// 3 = generation 2 head-major, 4 = generation 3, 5 = generation 3 head-major, 6 / 7 = as 4 / 5
+// without the instruction-interleave hints.
 static int g_prefill_variant = -1;
 VPSA_EXPORT int vpsa_set_prefill_variant(int v) {
   const int old = g_prefill_variant;
@@ -494,25 +1007,69 @@ VPSA_EXPORT int vpsa_set_prefill_variant(int v) {
   return old;
 }
 
+// Query rows per work-list entry for a GQA ratio and kernel selection (the host builds its tile
+// list with this height and passes it back to vpsa_paged_prefill).
+VPSA_EXPORT int vpsa_prefill_tile_rows(int n_q, int n_kv, int want64) {
+  if (n_kv <= 0 || n_q % n_kv != 0) return -1;
+  const int G = n_q / n_kv;
+  const int GP = G < 4 ? G : 4;
+  const int v = g_prefill_variant;
+  const bool gen3_ok = (G % 4) == 0;
+  if (gen3_ok && (v >= 4 || (v < 0 && want64))) return 64;
+  return 32 * (4 / GP);
+}
+
 VPSA_EXPORT int vpsa_paged_prefill(const void* q, long q_stride, void* out, long out_stride,
                                    const void* cache, long page_stride, long v_offset,
                                    const int* block_tables, int max_blocks, const int* cu_q,
                                    const int* ctx_lens, const int* tile_seq, const int* tile_q0,
-                                   int num_tiles, int num_seqs, int n_q, int n_kv, float scale,
-                                   hipStream_t stream) {
+                                   int num_tiles, int num_seqs, int tile_rows, int n_q, int n_kv,
+                                   float scale, hipStream_t stream) {
   if (num_tiles <= 0) return 0;
   if (n_q % n_kv != 0) return -1;
   const int G = n_q / n_kv;
   if (G == 3) return -1;  // the tile is 4 waves = GP heads x (4 / GP) row blocks: GP must divide 4
   const int GP = G < 4 ? G : 4;
-  dim3 grid(num_tiles, n_kv * ((G + GP - 1) / GP)), block(256);
   const float sl2 = scale * 1.4426950408889634f;
   int variant = g_prefill_variant;
-  if (variant < 0) variant = (num_seqs > 0 && num_tiles >= 8 * num_seqs) ? 3 : 2;
+  const bool many_tiles = num_seqs > 0 && num_tiles * (tile_rows / 32) >= 8 * num_seqs;
 #define VPSA_PREFILL_ARGS                                                                      \
   (const uint16_t*)q, q_stride, (uint16_t*)out, out_stride, (const uint16_t*)cache,             \
       page_stride, v_offset, block_tables, max_blocks, cu_q, ctx_lens, tile_seq, tile_q0, n_q,  \
       n_kv, sl2
+  if (tile_rows == 64 && G % 4 == 0) {  // (a ratio of 2 also has 64-row tiles: two waves per head)
+    if (variant >= 0 && variant < 4) return -2;
+    static bool attr_set = false;
+    if (!attr_set) {
+      const void* fns[4] = {(const void*)paged_prefill_kernel_v3<false, 1>,
+                            (const void*)paged_prefill_kernel_v3<true, 1>,
+                            (const void*)paged_prefill_kernel_v3<false, 0>,
+                            (const void*)paged_prefill_kernel_v3<true, 0>};
+      for (const void* f : fns)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 98304) != hipSuccess)
+          return -3;
+      attr_set = true;
+    }
+    dim3 grid(num_tiles, n_kv * (G / 4)), block(256);
+    if (variant < 0) variant = many_tiles ? 5 : 4;
+    if (variant == 5) {
+      hipLaunchKernelGGL((paged_prefill_kernel_v3<true, 1>), grid, block, 98304, stream,
+                         VPSA_PREFILL_ARGS);
+    } else if (variant == 4) {
+      hipLaunchKernelGGL((paged_prefill_kernel_v3<false, 1>), grid, block, 98304, stream,
+                         VPSA_PREFILL_ARGS);
+    } else if (variant == 7) {
+      hipLaunchKernelGGL((paged_prefill_kernel_v3<true, 0>), grid, block, 98304, stream,
+                         VPSA_PREFILL_ARGS);
+    } else {
+      hipLaunchKernelGGL((paged_prefill_kernel_v3<false, 0>), grid, block, 98304, stream,
+                         VPSA_PREFILL_ARGS);
+    }
+    return 0;
+  }
+  if (tile_rows != 32 * (4 / GP) || variant >= 4) return -2;
+  dim3 grid(num_tiles, n_kv * ((G + GP - 1) / GP)), block(256);
+  if (variant < 0) variant = many_tiles ? 3 : 2;
   if (variant == 0) {
     hipLaunchKernelGGL(paged_prefill_kernel, grid, block, 32768, stream, VPSA_PREFILL_ARGS);
   } else if (variant == 3) {

@@ -126,7 +126,7 @@ def test_disk_tier_after_host_eviction(tmp_path):
         eng.step()
     assert r.num_cached_tokens + r.num_external_tokens == 320 and r.num_external_tokens >= 192
     assert r.output_ids == first
-    assert len(list(tmp_path.glob("*.kv"))) > 0
+    assert len(list(tmp_path.rglob("*.kv"))) > 0  # under the model-identity directory
 
 
 def _serve_in_thread(coro_factory):
@@ -176,6 +176,94 @@ def test_remote_cache_shared_between_engines(serde):
         loop.call_soon_threadsafe(loop.stop)
 
 
+def test_remote_page_evicted_between_store_and_reload_is_a_cache_miss():
+    """The cache server is a bounded LRU: pages this replica uploaded can be gone when it wants
+    them back.  That is a cache miss (recompute from the first missing page), not an error, and
+    the HBM pages reserved for the load are given back."""
+    probe = engine()
+    page_bytes = probe.runner.pool[0].numel() * probe.runner.pool.element_size()
+    probe.shutdown()
+    # room for about two pages: every further upload evicts the oldest one
+    loop, srv = _serve_in_thread(lambda: CacheServer("127.0.0.1", 0, int(2.5 * page_bytes)).start())
+    url = f"lm://127.0.0.1:{srv.port}"
+    try:
+        eng = engine(pages=12, remote_url=url, remote_serde="naive")
+        free0 = eng.bm.num_free()
+        a, b, c = prompts(3, 330, seed=7)
+        first = eng.generate([a], copy.deepcopy(SP))[0]
+        eng.generate([b], copy.deepcopy(SP))
+        eng.generate([c], copy.deepcopy(SP))  # a's pages are out of HBM, most are out of the server too
+        import time
+
+        time.sleep(0.3)  # let the background uploads (and the evictions they cause) finish
+        r = eng.add_request(a, copy.deepcopy(SP))
+        while eng.has_work():
+            eng.step()  # must not raise
+        assert r.output_ids == first
+        assert r.num_cached_tokens + r.num_external_tokens < 320  # something had to be recomputed
+        assert eng.bm.num_free() == free0  # no page leaked by the failed load
+        eng.shutdown()
+    finally:
+        asyncio.run_coroutine_threadsafe(srv.stop(), loop).result(10)
+        loop.call_soon_threadsafe(loop.stop)
+
+
+def test_remote_server_gone_is_a_cache_miss():
+    loop, srv = _serve_in_thread(lambda: CacheServer("127.0.0.1", 0, 1 << 30).start())
+    url = f"lm://127.0.0.1:{srv.port}"
+    eng = engine(pages=12, remote_url=url, remote_serde="naive")
+    a, b, c = prompts(3, 330, seed=9)
+    first = eng.generate([a], copy.deepcopy(SP))[0]
+    eng.generate([b], copy.deepcopy(SP))
+    eng.generate([c], copy.deepcopy(SP))
+    asyncio.run_coroutine_threadsafe(srv.stop(), loop).result(10)
+    loop.call_soon_threadsafe(loop.stop)
+    r = eng.add_request(a, copy.deepcopy(SP))
+    while eng.has_work():
+        eng.step()
+    assert r.output_ids == first and r.num_external_tokens == 0
+    eng.shutdown()
+
+
+def test_two_models_on_one_cache_server_do_not_share_pages():
+    """Same tokenizer, same KV geometry, different weights identity: the chain hashes of a prompt
+    are equal, the keys in the shared server are not."""
+    loop, srv = _serve_in_thread(lambda: CacheServer("127.0.0.1", 0, 1 << 30).start())
+    url = f"lm://127.0.0.1:{srv.port}"
+    try:
+        def eng_named(name):
+            cfg = EngineConfig(model="tiny-llama", served_model_name=name, device="cpu", dtype="float32",
+                               max_model_len=1024, max_num_seqs=8, max_num_batched_tokens=256,
+                               num_gpu_blocks_override=24,
+                               kv_offload=KVOffloadConfig(remote_url=url, remote_serde="naive"), port=0)
+            return LLMEngine(cfg)
+
+        e1, e2, e3 = eng_named("base"), eng_named("fine-tune"), eng_named("base")
+        assert e1.connector.namespace != e2.connector.namespace == e2.connector.namespace
+        assert e1.connector.namespace == e3.connector.namespace
+        (a,) = prompts(1, 330, seed=11)
+        e1.generate([a], copy.deepcopy(SP))
+        import time
+
+        for _ in range(50):
+            if RemoteKVClient(url).stats().get("keys", 0) >= 5:
+                break
+            time.sleep(0.05)
+        r2 = e2.add_request(a, copy.deepcopy(SP))
+        while e2.has_work():
+            e2.step()
+        assert r2.num_external_tokens == 0  # another model's pages are invisible
+        r3 = e3.add_request(a, copy.deepcopy(SP))
+        while e3.has_work():
+            e3.step()
+        assert r3.num_external_tokens == 320  # a replica of the same model finds them
+        for e in (e1, e2, e3):
+            e.shutdown()
+    finally:
+        asyncio.run_coroutine_threadsafe(srv.stop(), loop).result(10)
+        loop.call_soon_threadsafe(loop.stop)
+
+
 @pytest.mark.parametrize("api_key", [None, "sekret"])
 def test_controller_reporting_and_pd_push(api_key):
     from vllm_production_stack_amd.controller import KVController, start_controller
@@ -206,10 +294,17 @@ def test_controller_reporting_and_pd_push(api_key):
 
         def run_prefill():
             sp = SamplingParams(max_tokens=1, temperature=0, ignore_eos=True)
-            pre.add_request(a, sp, kv_transfer_params={"do_remote_decode": True,
-                                                       "decode_target": f"http://127.0.0.1:{dport}"})
+            req = pre.add_request(a, sp, kv_transfer_params={"do_remote_decode": True,
+                                                             "decode_target": f"http://127.0.0.1:{dport}"})
             while pre.has_work():
                 pre.step()
+            # the step loop did not wait for the transfer: it runs on the push worker, and the
+            # request's HTTP handler would await this future before answering the router
+            fut = pre.connector.push_future(req.request_id)
+            assert fut is not None and pre.connector.push_future(req.request_id) is None
+            assert fut.result(30)["mode"] == "tcp"
+            pre.idle_tick()  # the references the worker held on the pages are given back
+            assert pre.bm.num_free() == 32
 
         await asyncio.get_running_loop().run_in_executor(None, run_prefill)
         # decode replica now holds the prompt's 5 full pages without having computed them

@@ -37,6 +37,14 @@ TARGETS = {
     "vpsa_routercore": ("cxx", ["routercore/routercore.cpp"], []),
 }
 
+# extra compile flags for single sources.  attention.hip: the one-wave-per-SIMD prefill kernel keeps
+# its score tiles in arch VGPRs (MFMA "VGPR form") and its output accumulators in AGPRs (inline
+# asm); without the flag every MFMA result of a 512-register kernel lands in AGPRs and has to be
+# copied out one register at a time before the softmax can read it.
+SOURCE_FLAGS = {
+    "kernels/attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+}
+
 # standalone executables: name -> (kind, sources, flags)
 BINARIES = {
     "vpsa-picker": ("cxx", ["routercore/picker_service.cpp", "routercore/routercore.cpp"], ["-lpthread"]),
@@ -76,7 +84,19 @@ def build_target(name: str, force: bool = False) -> Path | None:
         return None
     if not force and not _stale(out, paths):
         return out
-    if kind == "hip":
+    if kind == "hip" and any(src in SOURCE_FLAGS for src in srcs):
+        # sources with flags of their own: compile every source to an object, then link
+        objdir = HERE / "_obj" / name
+        objdir.mkdir(parents=True, exist_ok=True)
+        objs = []
+        for src, path in zip(srcs, paths):
+            obj = objdir / (path.stem + ".o")
+            if force or _stale(obj, [path]):
+                _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+                      "-I", str(CSRC), *SOURCE_FLAGS.get(src, []), "-c", str(path), "-o", str(obj)])
+            objs.append(str(obj))
+        cmd = [HIPCC, "--offload-arch=gfx950", *shared, *objs, "-o", str(out), *flags]
+    elif kind == "hip":
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", *shared,
                "-fvisibility=hidden", "-I", str(CSRC), *map(str, paths), "-o", str(out), *flags]
     else:

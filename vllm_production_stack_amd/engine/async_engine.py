@@ -89,6 +89,7 @@ class AsyncLLMEngine:
                         self._loop.call_soon_threadsafe(
                             self._deliver, [(o.request_id, o) for o in outs])
                 else:
+                    eng.idle_tick()
                     self._wake.wait(timeout=0.05)
                     self._wake.clear()
             except Exception as e:  # engine failure: fail every in-flight request
@@ -123,9 +124,10 @@ class AsyncLLMEngine:
         finally:
             self._queues.pop(request_id, None)
             self._live.pop(request_id, None)
-            if request_id in self.engine.requests:
-                self._inbox.append(("abort", request_id))
-                self._wake.set()
+            # always: the add may still be in the inbox (a client that went away at once), and an
+            # abort of an unknown or finished id is a no-op on the engine thread
+            self._inbox.append(("abort", request_id))
+            self._wake.set()
 
     def live_request(self, request_id: str):
         return self._live.get(request_id)

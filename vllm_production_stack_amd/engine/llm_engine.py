@@ -115,8 +115,16 @@ class LLMEngine:
         return self.scheduler.has_work()
 
     # ------------------------------------------------------------------ step
+    def idle_tick(self) -> None:
+        """Called by the serving loop when there is nothing to step: bookkeeping that normally
+        rides along with steps (references held for finished copies and pushes)."""
+        if self.connector is not None:
+            self.connector.poll()
+
     def step(self) -> list[StepOutput]:
         t_a = time.perf_counter()
+        if self.connector is not None:
+            self.connector.poll()
         out = self.scheduler.schedule()
         t_b = time.perf_counter()
         self.step_count += 1

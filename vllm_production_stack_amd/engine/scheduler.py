@@ -147,7 +147,16 @@ class Scheduler:
             n_ext = self.connector.lookup(rest)
             if n_ext > 0 and self.bm.can_allocate(n_ext):
                 new_pages = self.bm.allocate(n_ext)
-                req.load_event = self.connector.load_pages(rest[:n_ext], new_pages)
+                # a page that left the lower tiers after lookup() saw it is a cache miss: keep the
+                # leading pages that did arrive, give the rest back, recompute from there
+                try:
+                    req.load_event, n_ok = self.connector.load_pages(rest[:n_ext], new_pages)
+                except Exception:
+                    req.load_event, n_ok = None, 0
+                if n_ok < n_ext:
+                    self.bm.free(new_pages[n_ok:])
+                    new_pages = new_pages[:n_ok]
+                    n_ext = n_ok
                 for h, p in zip(rest[:n_ext], new_pages):
                     self.bm.register(p, h)
                 req.pages.extend(new_pages)

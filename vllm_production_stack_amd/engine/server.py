@@ -247,20 +247,26 @@ class EngineServer:
         return self._receiver
 
     async def kv_reserve(self, request):
-        d = await request.json()
         rcv = self._kv_receiver()
         try:
+            d = await request.json()
             res = await self.ae.call(lambda: rcv.reserve(d["hashes"], int(d["page_bytes"]), d))
-        except (ValueError, MemoryError) as e:
+        except (ValueError, KeyError, TypeError, MemoryError) as e:
             return _err(409, str(e), "KVTransferError")
         return web.json_response(res)
 
     async def kv_push(self, request):
-        raw = await request.read()
-        n = int.from_bytes(raw[:4], "little")
-        meta = json.loads(raw[4:4 + n])
         rcv = self._kv_receiver()
-        res = await self.ae.call(lambda: rcv.push(meta["pages"], raw[4 + n:]))
+        try:
+            raw = await request.read()
+            n = int.from_bytes(raw[:4], "little")
+            meta = json.loads(raw[4:4 + n])
+            pages = meta["pages"]
+            if not isinstance(pages, list):
+                raise ValueError("pages: a list of page indices")
+            res = await self.ae.call(lambda: rcv.push(pages, raw[4 + n:]))
+        except (ValueError, KeyError, TypeError) as e:  # malformed body or pages that are not reserved
+            return _err(409, str(e), "KVTransferError")
         return web.json_response(res)
 
     async def kv_rccl_init(self, request):
@@ -275,20 +281,33 @@ class EngineServer:
         return web.json_response(res)
 
     async def kv_rccl_recv(self, request):
-        d = await request.json()
         rcv = self._kv_receiver()
         try:
+            d = await request.json()
             res = await self.ae.call(lambda: rcv.rccl_recv(d["comm"], d["pages"], int(d["page_bytes"])))
-        except (KeyError, RuntimeError) as e:
+        except (KeyError, ValueError, TypeError, RuntimeError) as e:
             return _err(409, str(e), "KVTransferError")
         return web.json_response(res)
 
     async def kv_commit(self, request):
-        d = await request.json()
+        """Publish transferred pages.  The engine thread only enqueues the window -> pool copy and,
+        once its event has fired, registers the pages; the wait for the event runs on a worker
+        thread with a deadline (a dead RCCL sender cannot park the step loop)."""
         rcv = self._kv_receiver()
         try:
-            res = await self.ae.call(lambda: rcv.commit(d["hashes"], d["pages"], bool(d.get("landed"))))
-        except ValueError as e:
+            d = await request.json()
+            hashes, pages = d["hashes"], d["pages"]
+            ev = await self.ae.call(lambda: rcv.commit_begin(hashes, pages, bool(d.get("landed")),
+                                                             bool(d.get("rccl"))))
+            if ev is not None:
+                from ..parallel.kv_transfer import wait_event
+
+                arrived = await asyncio.get_running_loop().run_in_executor(None, wait_event, ev, 10.0)
+                if not arrived:
+                    await self.ae.call(lambda: rcv.commit_abort(hashes))
+                    return _err(409, "transferred KV pages did not arrive within 10 s", "KVTransferError")
+            res = await self.ae.call(lambda: rcv.commit_finish(hashes, pages))
+        except (KeyError, ValueError, TypeError, RuntimeError) as e:
             return _err(409, str(e), "KVTransferError")
         return web.json_response(res)
 
@@ -334,6 +353,20 @@ class EngineServer:
                 self._end_span(span, t0, None, 0, 0, 0.0, "error", error=repr(e))
             raise
 
+    async def _await_kv_push(self, rid, kvp) -> None:
+        """Prefill half of a disaggregated request: answer only when the pages are published on
+        the decode replica (or the transfer has failed: the decode replica then recomputes)."""
+        conn = self.engine.connector
+        if conn is None or not (kvp or {}).get("do_remote_decode"):
+            return
+        fut = conn.push_future(rid)
+        if fut is None:
+            return
+        try:
+            await asyncio.wait_for(asyncio.wrap_future(fut), timeout=35.0)
+        except Exception as e:  # logged by the connector's callback as well
+            log.warning("KV push of %s did not complete: %s", rid, e)
+
     async def _collect(self, rid, ids, params, lora, kvp, span, detok, t0):
         text = ""
         out_ids: list[int] = []
@@ -358,6 +391,7 @@ class EngineServer:
                 break
             if so.finished:
                 reason = so.finish_reason
+        await self._await_kv_push(rid, kvp)
         usage = {"prompt_tokens": len(ids), "completion_tokens": len(out_ids),
                  "total_tokens": len(ids) + len(out_ids)}
         if last is not None and last.num_cached_tokens:

@@ -48,9 +48,19 @@ class KVConnector:
         self.pool = r.pool
         self.device = r.device
         self.serde = PageSerde(mc.num_layers, r.n_kv_local, mc.head_dim, r.dtype, off.remote_serde)
+        # Pages of the lower tiers are keyed by the token chain hash, which says nothing about the
+        # weights that produced them.  Everything that leaves this process (remote server keys,
+        # disk files) is therefore namespaced by the model identity and the shard of it this rank
+        # holds: two models with the same tokenizer and KV geometry sharing one cache server (a
+        # base model and a fine-tune, a multi-model stack) can never load each other's pages.
+        # (The reference's LMCache keys carry model name and world size for the same reason.)
+        self.namespace = self._model_namespace(engine, r, mc)
         self.disk = None
         if off.max_local_disk_gb > 0:
-            self.disk = DiskKVStore(off.local_disk_path, int(off.max_local_disk_gb * (1 << 30)),
+            import os
+
+            self.disk = DiskKVStore(os.path.join(off.local_disk_path, self.namespace),
+                                    int(off.max_local_disk_gb * (1 << 30)),
                                     PageSerde(mc.num_layers, r.n_kv_local, mc.head_dim, r.dtype, "naive"))
         self.host = None
         if off.local_cpu or off.max_local_cpu_gb > 0:
@@ -76,6 +86,8 @@ class KVConnector:
                 self._stage_free.put(i)
             self._remote_stream = torch.cuda.Stream(device=self.device)
         self._pending: list[tuple[object, list[int]]] = []  # (event, page ids holding a ref)
+        self._pusher = None  # P->D push worker, created with the first transfer
+        self._push_futures: dict = {}  # request id -> future of its transfer
         self._bg: queue.Queue = queue.Queue()
         self._bg_thread = threading.Thread(target=self._bg_loop, name="kv-bg", daemon=True)
         self._bg_thread.start()
@@ -92,6 +104,22 @@ class KVConnector:
         self.metrics = m
 
     # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _model_namespace(engine, runner, mc) -> str:
+        import hashlib
+
+        from ..parallel.state import get_pp, get_tp
+
+        tp, pp = get_tp(), get_pp()
+        ident = "|".join(str(x) for x in (
+            engine.cfg.model, engine.cfg.model_name, runner.dtype, mc.num_layers, mc.hidden_size,
+            mc.head_dim, f"tp{tp.rank}of{tp.size}", f"pp{pp.rank}of{pp.size}",
+            getattr(engine.cfg, "kv_namespace", "") or ""))
+        return hashlib.sha1(ident.encode()).hexdigest()[:12]
+
+    def _key(self, h: int) -> bytes:
+        return RemoteKVClient.key(h, self.namespace + "/")
+
     def _self_ip(self) -> str:
         import os
 
@@ -144,7 +172,7 @@ class KVConnector:
             break
         if unknown and self.remote is not None:
             try:
-                flags = self.remote.exists_many([RemoteKVClient.key(h) for h in unknown])
+                flags = self.remote.exists_many([self._key(h) for h in unknown])
             except Exception as e:
                 log.warning("remote KV lookup failed: %s", e)
                 flags = []
@@ -172,59 +200,89 @@ class KVConnector:
         return out
 
     def load_pages(self, hashes: list[int], pages: list[int]):
-        """Start loading ``hashes`` into HBM ``pages``; returns an event-like object the runner
-        fences the compute stream on (or None when the data is already in place)."""
+        """Start loading ``hashes`` into HBM ``pages``.  Returns ``(fence, n_loaded)``: an
+        event-like object the runner fences the compute stream on (None when the data is already
+        in place) and the number of LEADING pages that were actually found.  A page that has left
+        the lower tiers since ``lookup`` saw it (the cache server is a bounded LRU and may have
+        restarted; a disk file may be gone), a server that does not answer and a blob that does
+        not decode are all cache misses: the caller recomputes from the first missing page on,
+        this method never raises."""
         t0 = time.time()
+        items = list(zip(hashes, pages))
+        idx_of = {h: i for i, h in enumerate(hashes)}
+        first_bad = len(items)
+
+        def bad(h: int, why) -> None:
+            nonlocal first_bad
+            self.remote_known.discard(h)
+            first_bad = min(first_bad, idx_of[h])
+            log.warning("KV page %016x is gone from the lower tiers (%s): recomputing from there", h, why)
+
         from_host, slow = [], []
-        for h, p in zip(hashes, pages):
+        for h, p in items:
             if self.host is not None and self.host.contains(h):
                 from_host.append((h, p))
             else:
                 slow.append((h, p))
-        if self._stage is not None and slow:
-            on_disk = [(h, p) for h, p in slow if self.disk is not None and self.disk.contains(h)]
-            fetched = [(h, p) for h, p in slow if (h, p) not in set(on_disk)]
-            missing = self._download_staged(fetched)
-            self.loaded_from["remote"] += len(fetched) - len(missing)
-            if self.host is not None:
-                done = [x for x in fetched if x not in set(missing)]
-                if done:
-                    self.host.store(done)
-            slow = on_disk + missing
-        elif self.remote is not None and self.serde.kind != 0 and slow:
-            on_disk = [(h, p) for h, p in slow if self.disk is not None and self.disk.contains(h)]
-            fetched = [x for x in slow if x not in set(on_disk)]
-            missing = self._download_codec(fetched)
-            self.loaded_from["remote"] += len(fetched) - len(missing)
-            if self.host is not None:
-                done = [x for x in fetched if x not in set(missing)]
-                if done:
-                    self.host.store(done)
-            slow = on_disk + missing
-        for h, p in slow:  # disk / remote: decode on this thread, then a plain H2D copy
-            t = self.disk.get(h, self.device) if self.disk is not None and self.disk.contains(h) else None
-            self.loaded_from["disk" if t is not None else "remote"] += 1
-            if t is None and self.remote is not None:
-                blob = self.remote.get(RemoteKVClient.key(h))
-                for _ in range(100):  # our own upload of this page may still be on its way
-                    if blob is not None or h not in self._inflight:
-                        break
-                    time.sleep(0.05)
-                    blob = self.remote.get(RemoteKVClient.key(h))
-                if blob is not None:
-                    t = self.serde.decode(blob, self.device)
+        try:
+            if self._stage is not None and slow:
+                on_disk = [(h, p) for h, p in slow if self.disk is not None and self.disk.contains(h)]
+                fetched = [(h, p) for h, p in slow if (h, p) not in set(on_disk)]
+                missing = self._download_staged(fetched)
+                self.loaded_from["remote"] += len(fetched) - len(missing)
+                if self.host is not None:
+                    done = [x for x in fetched if x not in set(missing)]
+                    if done:
+                        self.host.store(done)
+                slow = on_disk + missing
+            elif self.remote is not None and self.serde.kind != 0 and slow:
+                on_disk = [(h, p) for h, p in slow if self.disk is not None and self.disk.contains(h)]
+                fetched = [x for x in slow if x not in set(on_disk)]
+                missing = self._download_codec(fetched)
+                self.loaded_from["remote"] += len(fetched) - len(missing)
+                if self.host is not None:
+                    done = [x for x in fetched if x not in set(missing)]
+                    if done:
+                        self.host.store(done)
+                slow = on_disk + missing
+        except Exception as e:  # connection lost half way: what was not confirmed is looked at one by one
+            log.warning("bulk KV download failed: %s", e)
+        for h, p in sorted(slow, key=lambda x: idx_of[x[0]]):
+            if idx_of[h] >= first_bad:
+                break  # nothing behind the first missing page can be used
+            # disk / remote: decode on this thread, then a plain H2D copy
+            t = None
+            try:
+                t = self.disk.get(h, self.device) if self.disk is not None and self.disk.contains(h) else None
+                src = "disk"
+                if t is None and self.remote is not None:
+                    src = "remote"
+                    blob = self.remote.get(self._key(h))
+                    for _ in range(100):  # our own upload of this page may still be on its way
+                        if blob is not None or h not in self._inflight:
+                            break
+                        time.sleep(0.05)
+                        blob = self.remote.get(self._key(h))
+                    if blob is not None:
+                        t = self.serde.decode(blob, self.device)
+            except Exception as e:
+                bad(h, e)
+                continue
             if t is None:
-                raise KeyError(f"KV page {h:016x} vanished from the lower tiers")
+                bad(h, "not found")
+                continue
+            self.loaded_from[src] += 1
             self.pool[p].view(-1).copy_(t.view(-1))
             if self.host is not None:
                 self.host.store([(h, p)])
+        from_host = [(h, p) for h, p in from_host if idx_of[h] < first_bad]
         ev = self.host.load(from_host) if from_host else None
         self.loaded_from["host"] += len(from_host)
         dt = max(time.time() - t0, 1e-6)
-        self.metrics.kv_retrieve_speed.observe(len(hashes) * PAGE / dt)
+        self.metrics.kv_retrieve_speed.observe(first_bad * PAGE / dt)
         if ev is None:
-            return None
-        return _ComputeFence(self.host, ev)
+            return None, first_bad
+        return _ComputeFence(self.host, ev), first_bad
 
     def store_pages(self, fresh: list[tuple[int, int]]) -> None:
         """Write-through of newly filled pages (hash, page)."""
@@ -254,7 +312,7 @@ class KVConnector:
                     self._workers().submit(self._pack_and_put, h, sym, sc)
                 else:
                     blob = self.serde.encode(page)
-                    self._bg.put(lambda k=RemoteKVClient.key(h), b=blob: self.remote.put(k, b))
+                    self._bg.put(lambda k=self._key(h), b=blob: self.remote.put(k, b))
         elif self.disk is not None and self.host is None:
             for h, p in fresh:
                 self.disk.put(h, self.pool[p].cpu())
@@ -277,7 +335,7 @@ class KVConnector:
 
     def _pack_and_put(self, h: int, sym, sc) -> None:
         try:
-            if not self.remote.put(RemoteKVClient.key(h), self.serde.pack(sym, sc)):
+            if not self.remote.put(self._key(h), self.serde.pack(sym, sc)):
                 self.remote_known.discard(h)
         except Exception as e:
             self.remote_known.discard(h)
@@ -286,7 +344,7 @@ class KVConnector:
             self._inflight.discard(h)
 
     def _fetch_unpacked(self, h: int):
-        blob = self.remote.get(RemoteKVClient.key(h))
+        blob = self.remote.get(self._key(h))
         return None if blob is None else self.serde.unpack(blob)
 
     def _download_codec(self, items: list[tuple[int, int]]) -> list[tuple[int, int]]:
@@ -339,7 +397,7 @@ class KVConnector:
             for h, _p, slot in taken:
                 try:
                     view = memoryview(self._stage[slot].view(torch.uint8).numpy())
-                    if not self.remote.put_parts(RemoteKVClient.key(h), header, view):
+                    if not self.remote.put_parts(self._key(h), header, view):
                         self.remote_known.discard(h)
                 except Exception:
                     self.remote_known.discard(h)
@@ -368,7 +426,7 @@ class KVConnector:
                 used = []
                 slot = self._stage_free.get()
             view = memoryview(self._stage[slot].view(torch.uint8).numpy())
-            hdr = self.remote.get_page_into(RemoteKVClient.key(h), hdr_len, view)
+            hdr = self.remote.get_page_into(self._key(h), hdr_len, view)
             if hdr != want:
                 self._stage_free.put(slot)
                 left.append((h, p))
@@ -382,7 +440,9 @@ class KVConnector:
         return left
 
     def poll(self) -> None:
-        """Release page references whose offload copies have completed."""
+        """Release page references whose offload copies or P->D pushes have completed."""
+        if self._pusher is not None:
+            self._pusher.drain_released()
         still = []
         for ev, pages in self._pending:
             if ev.query():
@@ -406,35 +466,60 @@ class KVConnector:
         return self._pd_stats
 
     def on_request_finished(self, req) -> None:
+        """Engine thread, while the request still owns its pages.  A prefill request of a
+        disaggregated pair hands its pages to the push worker here: a reference per page, one
+        stream event, one queue put.  The transfer itself (control-plane round trips, the copy,
+        back-pressure of a busy decode replica) runs on that worker; the HTTP handler of the
+        request awaits ``push_future`` before it answers, so the router sends the decode request
+        only once the pages are published there."""
         kvp = req.kv_transfer_params or {}
         if not kvp.get("do_remote_decode") or self.role == "kv_consumer":
             return
         target = kvp.get("decode_target")
         if not target:
             return
-        from ..parallel.kv_transfer import push_request_pages
+        from ..parallel.kv_transfer import PagePusher, target_allowed
 
+        if not target_allowed(target):
+            log.error("KV push target %r refused (not http(s) or not in VPSA_PD_ALLOWED_TARGETS)", target)
+            return
         n_full = min(req.num_computed // PAGE, len(req.hashes), len(req.pages))
         if n_full == 0:
             return
-        t0 = time.time()
-        try:
-            mode = push_request_pages(self.engine, target, req.hashes[:n_full], req.pages[:n_full])
+        if self._pusher is None:
+            self._pusher = PagePusher(self.engine)
+        fut = self._pusher.submit(req.request_id, target, req.hashes[:n_full], req.pages[:n_full])
+        self._push_futures[req.request_id] = fut
+        rid = req.request_id
+
+        def done(f, rid=rid, target=target, n=n_full):
             st = self.pd_stats
+            if f.exception() is not None:
+                st["failed"] = st.get("failed", 0) + 1
+                log.error("KV push of %s to %s failed: %s", rid, target, f.exception())
+                return
+            r = f.result()
             st["pushes"] += 1
-            st["pages"] += n_full
-            st["seconds"] += time.time() - t0
-            st["by_mode"][mode] = st["by_mode"].get(mode, 0) + 1
-            log.info("pushed %d KV pages of %s to %s via %s in %.1f ms", n_full, req.request_id,
-                     target, mode, (time.time() - t0) * 1e3)
-        except Exception as e:
-            log.error("KV push to %s failed: %s", target, e)
+            st["pages"] += n
+            st["seconds"] += r["seconds"]
+            st["by_mode"][r["mode"]] = st["by_mode"].get(r["mode"], 0) + 1
+            log.info("pushed %d KV pages of %s to %s via %s in %.1f ms", n, rid, target, r["mode"],
+                     r["seconds"] * 1e3)
+
+        fut.add_done_callback(done)
+
+    def push_future(self, request_id: str):
+        """The transfer started for ``request_id`` when it finished (None: there was none).  Taken
+        once: the caller owns it."""
+        return self._push_futures.pop(request_id, None)
 
     def close(self) -> None:
         if self._closed:
             return
         self._closed = True
         self._bg.put(None)
+        if self._pusher is not None:
+            self._pusher.close()
         if self._pool_exec is not None:
             self._pool_exec.shutdown(wait=True)
         for ev, pages in self._pending:

@@ -30,6 +30,7 @@ class BatchMeta:
     pre_ctx_lens: torch.Tensor | None = None  # int32 [num_prefill_seqs]
     pre_tile_seq: torch.Tensor | None = None
     pre_tile_q0: torch.Tensor | None = None
+    pre_tile_rows: int | None = None  # tile height the work list was built for
     # rows whose logits are needed (last row of every sequence that samples this step)
     logits_rows: torch.Tensor | None = None  # int64 [num_out]
     # per-row LoRA slot (-1 = base model), only when adapters are active

@@ -93,7 +93,7 @@ class OPTModel:
             if meta.num_prefill_seqs > 0:
                 ops.paged_prefill(q[nd:], out[nd:], pool, li, meta.pre_block_tables, meta.pre_cu_q,
                                   meta.pre_ctx_lens, meta.pre_tile_seq, meta.pre_tile_q0, nq, nkv,
-                                  d, self.scale)
+                                  d, self.scale, meta.pre_tile_rows)
             h = h + F.linear(out, lw["wo"], lw["bo"])
             x = reference.layer_norm(h, lw["ln2_w"], lw["ln2_b"], 1e-5)
             a = F.linear(x, lw["fc1"], lw["b1"])

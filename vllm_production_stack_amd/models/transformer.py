@@ -170,7 +170,7 @@ class TransformerModel:
         if meta.num_prefill_seqs > 0:
             ops.paged_prefill(q[nd:], out[nd:], pool, layer, meta.pre_block_tables, meta.pre_cu_q,
                               meta.pre_ctx_lens, meta.pre_tile_seq, meta.pre_tile_q0, nq, nkv, d,
-                              self.scale)
+                              self.scale, meta.pre_tile_rows)
         del cfg
         return out
 

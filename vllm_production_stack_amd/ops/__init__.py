@@ -28,7 +28,7 @@ def _kernels():
         lib = _native.load("vpsa_kernels")
         for name in (
             "vpsa_rmsnorm", "vpsa_rope_cache", "vpsa_silu_mul", "vpsa_argmax_bf16",
-            "vpsa_paged_prefill", "vpsa_set_prefill_variant", "vpsa_set_decode_variant", "vpsa_paged_decode", "vpsa_kv_gather_pages",
+            "vpsa_paged_prefill", "vpsa_set_prefill_variant", "vpsa_prefill_tile_rows", "vpsa_set_decode_variant", "vpsa_paged_decode", "vpsa_kv_gather_pages",
             "vpsa_kv_scatter_pages", "vpsa_cachegen_encode", "vpsa_cachegen_decode",
             "vpsa_moe_topk_softmax", "vpsa_moe_align", "vpsa_moe_permute", "vpsa_moe_combine",
             "vpsa_moe_gemv", "vpsa_moe_mfma", "vpsa_lora_shrink", "vpsa_lora_expand",
@@ -50,7 +50,9 @@ def native_loaded() -> bool:
 def set_prefill_variant(v: int) -> int:
     """Select the prefill attention kernel (for in-process A/B timing and tests): -1 automatic,
     0 first generation, 1 second generation without wave priorities, 2 second generation,
-    3 second generation with head-major tile order.  Returns the previous selection."""
+    3 second generation with head-major tile order, 4 / 5 third generation (64-row tiles, one wave
+    per SIMD) in plain / head-major tile order, 6 / 7 the same without the hand-interleaved
+    instruction stream.  Returns the previous selection."""
     return int(_kernels().vpsa_set_prefill_variant(c_int(v)))
 
 
@@ -162,11 +164,23 @@ def rope_and_cache(qkv, positions, slots, cos_sin, pool, layer, n_q, n_kv, head_
 
 
 # --------------------------------------------------------------------------- attention
-def build_prefill_tiles(q_lens, n_q, n_kv):
+def prefill_tile_rows(q_lens, n_q, n_kv) -> int:
+    """Query rows per work-list entry.  The third-generation kernel works on 64-row tiles (one
+    GQA group of 4 heads x 64 rows per workgroup) and is taken whenever the GQA ratio is a
+    multiple of 4.  The choice deliberately does not look at the batch: two kernels round
+    differently, and a request's tokens must not depend on what shares its step."""
+    del q_lens
+    rows = int(_kernels().vpsa_prefill_tile_rows(c_int(n_q), c_int(n_kv), c_int(1)))
+    if rows <= 0:
+        raise ValueError(f"paged_prefill: unsupported head layout n_q={n_q} n_kv={n_kv}")
+    return rows
+
+
+def build_prefill_tiles(q_lens, n_q, n_kv, rows=None):
     """Host-side work list for the prefill kernel: one (sequence, first row) entry per query
-    tile, longest-context tiles first so the heaviest workgroups start earliest."""
-    g = n_q // n_kv
-    qt = 32 * (4 // min(g, 4))
+    tile of ``rows`` rows (default: ``prefill_tile_rows``), longest-context tiles first so the
+    heaviest workgroups start earliest."""
+    qt = rows or prefill_tile_rows(q_lens, n_q, n_kv)
     seqs, q0s = [], []
     for s, ql in enumerate(q_lens):
         for q0 in range(0, ql, qt):
@@ -177,7 +191,9 @@ def build_prefill_tiles(q_lens, n_q, n_kv):
 
 
 def paged_prefill(q, out, pool, layer, block_tables, cu_q, ctx_lens, tile_seq, tile_q0, n_q, n_kv,
-                  head_dim, scale):
+                  head_dim, scale, tile_rows=None):
+    """``tile_rows``: the tile height ``tile_seq`` / ``tile_q0`` were built for (default: the
+    32-row-wave layout of the first two kernel generations)."""
     if _generic_attention(q, head_dim):
         return reference.paged_prefill(q, out, pool, layer, block_tables, cu_q, ctx_lens, n_q,
                                        n_kv, head_dim, scale)
@@ -186,13 +202,15 @@ def paged_prefill(q, out, pool, layer, block_tables, cu_q, ctx_lens, tile_seq, t
         assert t.dtype == torch.int32 and t.is_cuda and t.is_contiguous()
     assert tile_seq.numel() == tile_q0.numel()
     assert cu_q.numel() == ctx_lens.numel() + 1 and block_tables.shape[0] >= ctx_lens.numel()
+    if tile_rows is None:
+        tile_rows = 32 * (4 // min(n_q // n_kv, 4))
     base = pool.data_ptr() + layer * pool.stride(1) * 2
     rc = _kernels().vpsa_paged_prefill(
         _p(q), c_long(q.stride(0)), _p(out), c_long(out.stride(0)), c_void_p(base),
         c_long(pool.stride(0)), c_long(pool.stride(2)), _p(block_tables),
         c_int(block_tables.stride(0)), _p(cu_q), _p(ctx_lens), _p(tile_seq), _p(tile_q0),
-        c_int(tile_seq.numel()), c_int(ctx_lens.numel()), c_int(n_q), c_int(n_kv), c_float(scale),
-        _stream())
+        c_int(tile_seq.numel()), c_int(ctx_lens.numel()), c_int(tile_rows), c_int(n_q), c_int(n_kv),
+        c_float(scale), _stream())
     _check(rc, "paged_prefill")
 
 

@@ -14,11 +14,21 @@ Protocol (control plane = the replicas' own HTTP ports, data plane chosen per pa
               rounds (reserve -> push -> commit, repeated),
         rccl  ncclSend / ncclRecv of whole pages on side streams, over a two-rank RCCL
               communicator created per (prefill, decode) pair (the unique id travels over the
-              control plane); for GPUs that cannot exchange IPC handles (other node, other
-              container namespace).  Opt-in: VPSA_PD_TRANSPORT=rccl,
+              control plane).  Taken automatically when both replicas have a GPU and the decode
+              replica offers no landing window to this producer (another host or container
+              namespace, or its hipIpc export failed); VPSA_PD_TRANSPORT=rccl forces it,
         tcp   POST <decode>/kv/push with the raw page bytes (any host, CPU tests);
   3. producer  POST <decode>/kv/commit {hashes, pages} -> pages are published in the decode
      replica's prefix cache; the decode request then finds its prompt resident.
+
+Neither side's step loop waits for a transfer.  On the prefill replica the engine thread only
+takes a reference on the finished request's pages, records a stream event and hands the job to a
+worker thread (``PagePusher``) with a stream of its own; the HTTP handler of the prefill request
+awaits the job's future before it answers the router, so the decode request is sent only when the
+pages are published.  On the decode replica ``commit`` enqueues the window -> pool copy on a side
+stream, a worker thread waits for its event (bounded), and only then are the pages registered in
+the prefix cache: whoever finds them there finds complete data, and nothing ever calls a
+device-wide synchronise.
 Reference behaviour being provided: the NIXL sender/receiver pair configured by
 LMCACHE_NIXL_* (/root/reference/helm/templates/deployment-vllm-multi.yaml:267-305) and the
 router's two-phase request flow (/root/reference/src/vllm_router/services/request_service/request.py:339-431).
@@ -41,6 +51,54 @@ _comm = None
 _api_key: str | None = None  # bearer token of the deployment's replicas (they share VLLM_API_KEY)
 _peer_maps: dict[tuple[str, str], int] = {}  # (target url, handle) -> mapped base of its landing window
 _rccl_peers: dict[str, tuple[int, str]] = {}  # target url -> (communicator, key on the decode side)
+_rccl_broken: set[str] = set()  # targets whose RCCL setup failed once: not tried again
+# Test hook: with a stub comm library installed in ``_comm`` the device code paths (landing
+# window, RCCL) run against CPU tensors, so their control flow is covered without a GPU.
+_FAKE_DEVICE = False
+
+
+def _on_device(pool) -> bool:
+    return bool(pool.is_cuda or _FAKE_DEVICE)
+
+
+class _DoneEvent:
+    def query(self) -> bool:
+        return True
+
+    def synchronize(self) -> None:
+        return None
+
+
+def _new_stream(pool):
+    return torch.cuda.Stream(device=pool.device) if pool.is_cuda else None
+
+
+def _stream_ptr(stream):
+    return c_void_p(stream.cuda_stream if stream is not None else 0)
+
+
+def _record(stream):
+    if stream is None:
+        return _DoneEvent()
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    return ev
+
+
+def _device_index(pool) -> int:
+    return (pool.device.index or 0) if pool.is_cuda else 0
+
+
+def wait_event(ev, timeout_s: float) -> bool:
+    """Host-side bounded wait for a stream event (never on the engine thread)."""
+    import time
+
+    deadline = time.time() + timeout_s
+    while not ev.query():
+        if time.time() > deadline:
+            return False
+        time.sleep(0.0005)
+    return True
 
 
 def host_identity() -> str:
@@ -99,7 +157,7 @@ def comm():
     return _comm
 
 
-def _post(url: str, payload: dict, raw: bytes | None = None, timeout: float = 60.0) -> dict:
+def _post(url: str, payload: dict, raw: bytes | None = None, timeout: float = 10.0) -> dict:
     if raw is None:
         data = json.dumps(payload).encode()
         headers = {"Content-Type": "application/json"}
@@ -147,12 +205,38 @@ def export_ipc_handle(pool: torch.Tensor) -> tuple[str, int] | None:
         return None
 
 
-def push_request_pages(engine, target: str, hashes: list[int], pages: list[int]) -> str:
-    """Producer side: make ``hashes`` resident on the decode replica at ``target``.  The calls carry
-    this replica's API key: the replicas of one deployment are started with the same VLLM_API_KEY
+def target_allowed(target: str) -> bool:
+    """A push goes to an http(s) URL; when VPSA_PD_ALLOWED_TARGETS (comma-separated URL prefixes or
+    host names) is set, only to one of those.  The router overwrites whatever ``kv_transfer_params``
+    a client sent; this is the engine's own line of defence against being told to POST KV bytes and
+    the deployment's bearer token somewhere else."""
+    import os
+    from urllib.parse import urlparse
+
+    try:
+        u = urlparse(target)
+    except ValueError:
+        return False
+    if u.scheme not in ("http", "https") or not u.hostname:
+        return False
+    allow = [x.strip() for x in os.environ.get("VPSA_PD_ALLOWED_TARGETS", "").split(",") if x.strip()]
+    if not allow:
+        return True
+    return any(target.startswith(a) or u.hostname == a or f"{u.hostname}:{u.port}" == a for a in allow)
+
+
+def push_request_pages(engine, target: str, hashes: list[int], pages: list[int], ready=None,
+                       stream=None, deadline_s: float = 30.0) -> str:
+    """Producer side: make ``hashes`` resident on the decode replica at ``target``.  Runs on the
+    pusher's worker thread (``stream``: its side stream, ``ready``: event recorded on the compute
+    stream when the request finished; the copies wait for it on the device).  Every control-plane
+    call has a short timeout and the whole push one deadline: a slow or dead decode replica costs
+    this request its transfer, never the replica its step loop.  The calls carry this replica's
+    API key: the replicas of one deployment are started with the same VLLM_API_KEY
     (/root/reference/helm/templates/deployment-vllm-multi.yaml:216-230), and the decode replica's
     /kv/* endpoints sit behind the same bearer check as its OpenAI endpoints."""
     import os
+    import time
 
     global _api_key
     _api_key = getattr(engine.cfg, "api_key", None) or os.environ.get("VLLM_API_KEY") or None
@@ -162,15 +246,26 @@ def push_request_pages(engine, target: str, hashes: list[int], pages: list[int])
     idx = {h: i for i, h in enumerate(hashes)}
     pref = transport_preference()
     used = "resident"
-    import time
+    on_dev = _on_device(pool)
+    if on_dev and stream is None:
+        stream = _new_stream(pool)
+    if stream is not None:
+        if ready is not None:
+            stream.wait_event(ready)
+        else:
+            stream.wait_stream(torch.cuda.current_stream(pool.device))
 
-    rounds, deadline = 0, time.time() + 20.0
+    t_end = time.time() + deadline_s
+    busy_until = time.time() + min(10.0, deadline_s / 2)
+    rounds = 0
     while rounds < len(hashes) + 2:  # one round per landing-window fill; bounded in any case
+        if time.time() > t_end:
+            raise TimeoutError(f"KV push to {target} exceeded {deadline_s:.0f} s")
         res = _post(target + "/kv/reserve", {"hashes": hashes, "page_bytes": page_bytes, "source_rank": _my_rank(),
-                                             "host_id": host_identity(), "transport": pref, "gpu": bool(pool.is_cuda)})
+                                             "host_id": host_identity(), "transport": pref, "gpu": on_dev})
         if res.get("busy"):  # the window is full of other producers' pages
-            if time.time() > deadline:
-                pref = "tcp"  # the next reserve asks for pool pages and the bytes go over the control plane
+            if time.time() > busy_until:
+                pref = "tcp" if pref != "rccl" else pref  # the next reserve asks for pool pages
             time.sleep(0.002)
             continue
         rounds += 1
@@ -180,29 +275,110 @@ def push_request_pages(engine, target: str, hashes: list[int], pages: list[int])
             break
         src = [pages[idx[h]] for h in missing]
         mode = "tcp"
-        if pool.is_cuda and res.get("ipc_handle") and res.get("ipc_slots") is not None:
+        if on_dev and res.get("ipc_handle") and res.get("ipc_slots") is not None:
             try:
-                _push_ipc(pool, target, res["ipc_handle"], res.get("ipc_offset", 0), page_bytes, src, res["ipc_slots"])
+                _push_ipc(pool, target, res["ipc_handle"], res.get("ipc_offset", 0), page_bytes, src,
+                          res["ipc_slots"], stream)
                 mode = "ipc"
             except Exception as e:
                 log.warning("ipc push failed (%s); falling back", e)
-        if mode == "tcp" and pool.is_cuda and pref == "rccl" and res.get("gpu"):
+        # RCCL when forced, or when both sides have a GPU and no landing window came back (another
+        # host or namespace, or the export failed): a multi-node deployment uses it by itself
+        want_rccl = pref == "rccl" or (pref == "auto" and res.get("ipc_slots") is None)
+        if mode == "tcp" and on_dev and res.get("gpu") and want_rccl and target not in _rccl_broken:
             try:
-                _push_rccl(pool, target, page_bytes, src, dst_pages)
+                _push_rccl(pool, target, page_bytes, src, dst_pages, stream)
                 mode = "rccl"
             except Exception as e:
-                log.warning("rccl push failed (%s); falling back to tcp", e)
+                _rccl_broken.add(target)
+                log.warning("rccl push failed (%s); this pair uses tcp from now on", e)
         if mode == "tcp":
             chunk = 8
             for i in range(0, len(src), chunk):
-                blob = pool[torch.tensor(src[i:i + chunk], device=pool.device)].contiguous().cpu()
+                if stream is not None:
+                    with torch.cuda.stream(stream):
+                        blob = pool[torch.tensor(src[i:i + chunk], device=pool.device)].contiguous().cpu()
+                else:
+                    blob = pool[torch.tensor(src[i:i + chunk])].contiguous()
                 raw = blob.view(torch.uint8).numpy().tobytes()
                 _post(target + "/kv/push", {"pages": dst_pages[i:i + chunk], "page_bytes": page_bytes}, raw)
-        _post(target + "/kv/commit", {"hashes": missing, "pages": dst_pages, "landed": mode == "ipc"})
+        _post(target + "/kv/commit", {"hashes": missing, "pages": dst_pages, "landed": mode == "ipc",
+                                      "rccl": mode == "rccl"}, timeout=15.0)
         used = mode
         if not res.get("more"):
             break
     return used
+
+
+class PagePusher:
+    """Worker thread of a prefill replica that moves finished requests' pages to their decode
+    replicas.  ``submit`` is called on the engine thread and returns at once with a future; the
+    pages stay referenced until the job is over, and ``drain_released`` (engine thread again)
+    gives the references back."""
+
+    def __init__(self, engine):
+        import queue
+        import threading
+
+        self.engine = engine
+        self._jobs: "queue.Queue" = queue.Queue()
+        self._released: "queue.Queue" = queue.Queue()
+        self._stream = None
+        self._thread = threading.Thread(target=self._loop, name="kv-push", daemon=True)
+        self._thread.start()
+
+    def submit(self, request_id: str, target: str, hashes: list[int], pages: list[int]):
+        from concurrent.futures import Future
+
+        pool = self.engine.runner.pool
+        bm = self.engine.bm
+        for p in pages:  # the request is about to give its pages back: keep them until the push is over
+            bm.ref[p] += 1
+        ready = None
+        if pool.is_cuda:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(pool.device))
+        fut: Future = Future()
+        self._jobs.put((request_id, target, list(hashes), list(pages), ready, fut))
+        return fut
+
+    def drain_released(self) -> None:
+        """Engine thread: give back the page references of finished pushes."""
+        import queue
+
+        while True:
+            try:
+                pages = self._released.get_nowait()
+            except queue.Empty:
+                return
+            self.engine.bm.free(pages)
+
+    def _loop(self) -> None:
+        import time
+
+        pool = self.engine.runner.pool
+        if pool.is_cuda:
+            from .. import ops
+
+            ops.ensure_device()
+            torch.cuda.set_device(pool.device)
+            self._stream = torch.cuda.Stream(device=pool.device)
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                return
+            request_id, target, hashes, pages, ready, fut = job
+            t0 = time.time()
+            try:
+                mode = push_request_pages(self.engine, target, hashes, pages, ready, self._stream)
+                fut.set_result({"mode": mode, "pages": len(pages), "seconds": time.time() - t0})
+            except BaseException as e:  # the future must always complete
+                fut.set_exception(e)
+            finally:
+                self._released.put(pages)
+
+    def close(self) -> None:
+        self._jobs.put(None)
 
 
 def _my_rank() -> int:
@@ -211,7 +387,7 @@ def _my_rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else -1
 
 
-def _push_ipc(pool, target, handle_hex, offset, page_bytes, src_pages, dst_slots) -> None:
+def _push_ipc(pool, target, handle_hex, offset, page_bytes, src_pages, dst_slots, stream=None) -> None:
     """Copy pool pages into slots of the peer's landing window."""
     lib = comm()
     base = _peer_maps.get((target, handle_hex))
@@ -226,16 +402,18 @@ def _push_ipc(pool, target, handle_hex, offset, page_bytes, src_pages, dst_slots
     n = len(src_pages)
     sp = (ctypes.c_int64 * n)(*src_pages)
     dp = (ctypes.c_int64 * n)(*dst_slots)
-    stream = torch.cuda.Stream(device=pool.device)
-    stream.wait_stream(torch.cuda.current_stream(pool.device))
+    if stream is None and pool.is_cuda:
+        stream = _new_stream(pool)
+        stream.wait_stream(torch.cuda.current_stream(pool.device))
     rc = lib.comm_push_pages(c_void_p(pool.data_ptr()), c_void_p(base + offset), page_bytes,
-                             sp, dp, n, c_void_p(stream.cuda_stream))
+                             sp, dp, n, _stream_ptr(stream))
     if rc != 0:
         raise RuntimeError(f"comm_push_pages failed ({rc})")
-    stream.synchronize()
+    if stream is not None:
+        stream.synchronize()  # the caller's thread, never the engine's
 
 
-def _push_rccl(pool, target, page_bytes, src_pages, dst_pages) -> None:
+def _push_rccl(pool, target, page_bytes, src_pages, dst_pages, stream=None) -> None:
     """ncclSend the pages; the decode replica posts the matching ncclRecv first."""
     import threading
 
@@ -251,13 +429,13 @@ def _push_rccl(pool, target, page_bytes, src_pages, dst_pages) -> None:
 
         def join_remote():
             try:
-                _post(target + "/kv/rccl_init", {"id": key}, timeout=120.0)
+                _post(target + "/kv/rccl_init", {"id": key}, timeout=60.0)
             except Exception as e:  # surfaced after our own init returns or times out
                 err.append(e)
 
         th = threading.Thread(target=join_remote, daemon=True)
         th.start()
-        c = lib.comm_rccl_init(uid, 2, 0, pool.device.index or 0)
+        c = lib.comm_rccl_init(uid, 2, 0, _device_index(pool))
         th.join()
         if err or not c:
             raise RuntimeError(f"RCCL communicator setup failed: {err[0] if err else 'ncclCommInitRank'}")
@@ -265,20 +443,24 @@ def _push_rccl(pool, target, page_bytes, src_pages, dst_pages) -> None:
         _rccl_peers[target] = ent
     c, key = ent
     n = len(src_pages)
+    # recv before send: the decode replica has its ncclRecv calls enqueued when this returns
     _post(target + "/kv/rccl_recv", {"comm": key, "pages": dst_pages, "page_bytes": page_bytes})
     sp = (ctypes.c_int64 * n)(*src_pages)
-    stream = torch.cuda.Stream(device=pool.device)
-    stream.wait_stream(torch.cuda.current_stream(pool.device))
+    if stream is None and pool.is_cuda:
+        stream = _new_stream(pool)
+        stream.wait_stream(torch.cuda.current_stream(pool.device))
     rc = lib.comm_rccl_send_pages(c_void_p(c), c_void_p(pool.data_ptr()), page_bytes, sp, n, 1,
-                                  c_void_p(stream.cuda_stream))
+                                  _stream_ptr(stream))
     if rc != 0:
         raise RuntimeError(f"ncclSend failed ({rc})")
-    stream.synchronize()
+    if stream is not None and not wait_event(_record(stream), 20.0):
+        raise TimeoutError("ncclSend did not complete within 20 s")
 
 
 # ------------------------------------------------------------------ decode side (engine thread)
 class KVReceiver:
-    """Runs inside the decode replica; methods are invoked on the engine thread."""
+    """Runs inside the decode replica; methods are invoked on the engine thread (except
+    ``rccl_init``, which blocks in the communicator rendezvous on a worker thread)."""
 
     def __init__(self, engine):
         self.engine = engine
@@ -294,6 +476,8 @@ class KVReceiver:
         self.reserve_ttl = float(os.environ.get("VPSA_PD_RESERVE_TTL_S", "120"))
         self._rccl: dict[str, int] = {}  # unique id (hex) -> communicator with one prefill replica
         self._rccl_stream = None
+        self._rccl_event = None  # completion of the receives posted last
+        self._copy_stream = None  # window -> pool copies
 
     def _landing_window(self, page_bytes: int) -> bool:
         """Allocate and export the landing window on first use; False when there is none."""
@@ -339,6 +523,16 @@ class KVReceiver:
             log.warning("dropped %d KV transfer reservations older than %.0f s", len(old), self.reserve_ttl)
         return len(old)
 
+    def _require_reserved(self, pages: list[int]) -> None:
+        """Page indices in a push / receive / commit come from another process: they must be pages
+        this receiver handed out and still holds for a transfer.  Anything else (a reservation
+        that expired and whose page now belongs to a running request, an index outside the pool,
+        a client making things up) is refused before a byte is written."""
+        live = set(self.reserved.values())
+        bad = [p for p in pages if not isinstance(p, int) or isinstance(p, bool) or p not in live]
+        if bad:
+            raise ValueError(f"pages {bad[:4]} are not reserved for a transfer (the reservation expired?)")
+
     def reserve(self, hashes: list[int], page_bytes: int, peer: dict | None = None) -> dict:
         """``peer``: what the producer said about itself (host_id, transport, gpu); a producer on
         this host with a GPU gets landing-window slots, as many pages as there are free slots."""
@@ -347,13 +541,16 @@ class KVReceiver:
         mine = pool.stride(0) * pool.element_size()
         if page_bytes != mine:
             raise ValueError(f"page size mismatch: sender {page_bytes}, receiver {mine}")
+        if not isinstance(hashes, list) or not all(isinstance(h, int) and not isinstance(h, bool) for h in hashes):
+            raise ValueError("hashes: a list of integers")
         if self._reserved_at:
             self._expire()
         missing = [h for h in hashes if not bm.contains(h) and h not in self.reserved]
         peer = peer or {}
         slots = None
         more = False
-        by_ipc = bool(missing and pool.is_cuda and peer.get("gpu") and peer.get("host_id") == host_identity() and
+        on_dev = _on_device(pool)
+        by_ipc = bool(missing and on_dev and peer.get("gpu") and peer.get("host_id") == host_identity() and
                       peer.get("transport", "auto") in ("auto", "ipc") and self._landing_window(page_bytes))
         if by_ipc and not self._free_slots:
             # other producers fill the window right now: their commits free it within milliseconds
@@ -378,72 +575,114 @@ class KVReceiver:
                 self._slot_of[h] = slots[i]
         return {"pages": pages, "missing": missing, "more": more,
                 "ipc_handle": self._landing_handle if slots is not None else None, "ipc_offset": 0,
-                "ipc_slots": slots, "host_id": host_identity(), "gpu": bool(pool.is_cuda)}
+                "ipc_slots": slots, "host_id": host_identity(), "gpu": on_dev}
 
     def rccl_init(self, key: str) -> dict:
         """Join the two-rank communicator a prefill replica is creating (blocks until it joined)."""
         pool = self.engine.runner.pool
-        if not pool.is_cuda:
+        if not _on_device(pool):
             raise ValueError("RCCL transport needs a GPU replica")
         if key not in self._rccl:
             uid = bytes.fromhex(key)
-            c = comm().comm_rccl_init(ctypes.create_string_buffer(uid, len(uid)), 2, 1, pool.device.index or 0)
+            c = comm().comm_rccl_init(ctypes.create_string_buffer(uid, len(uid)), 2, 1, _device_index(pool))
             if not c:
                 raise RuntimeError("ncclCommInitRank failed")
             self._rccl[key] = c
         return {"ok": True}
 
     def rccl_recv(self, key: str, pages: list[int], page_bytes: int) -> dict:
-        """Post ncclRecv for ``pages`` on the receive stream; ``commit`` waits for completion."""
+        """Post ncclRecv for ``pages`` on the receive stream; ``commit`` waits (bounded, off the
+        engine thread) for their completion event."""
         pool = self.engine.runner.pool
+        if page_bytes != pool.stride(0) * pool.element_size():
+            raise ValueError("page size mismatch")
+        self._require_reserved(pages)
         c = self._rccl[key]
-        if self._rccl_stream is None:
-            self._rccl_stream = torch.cuda.Stream(device=pool.device)
-        self._rccl_stream.wait_stream(torch.cuda.current_stream(pool.device))
+        if self._rccl_stream is None and pool.is_cuda:
+            self._rccl_stream = _new_stream(pool)
         n = len(pages)
         dp = (ctypes.c_int64 * n)(*pages)
         rc = comm().comm_rccl_recv_pages(c_void_p(c), c_void_p(pool.data_ptr()), page_bytes, dp, n, 0,
-                                         c_void_p(self._rccl_stream.cuda_stream))
+                                         _stream_ptr(self._rccl_stream))
         if rc != 0:
             raise RuntimeError(f"ncclRecv failed ({rc})")
+        self._rccl_event = _record(self._rccl_stream)
         return {"ok": True}
 
     def push(self, pages: list[int], raw: bytes) -> dict:
+        """TCP data plane: page bytes arrive in the request body."""
         pool = self.engine.runner.pool
         n = len(pages)
+        page_bytes = pool.stride(0) * pool.element_size()
+        self._require_reserved(pages)
+        if len(raw) != n * page_bytes:
+            raise ValueError(f"payload of {len(raw)} bytes for {n} pages of {page_bytes}")
         t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).view(pool.dtype).view(n, *pool.shape[1:])
-        pool[torch.tensor(pages, device=pool.device)] = t.to(pool.device)
+        pool[torch.tensor(pages, device=pool.device)] = t.to(pool.device, non_blocking=False)
         return {"ok": True}
 
-    def commit(self, hashes: list[int], pages: list[int], landed: bool = False) -> dict:
-        """Publish transferred pages.  ``landed``: the bytes are in the landing window (the
-        producer has synchronised its copy stream); they move into the pool pages first.  Slots
-        are returned either way."""
-        bm = self.engine.bm
+    # commit = begin (engine thread: validate, enqueue the window -> pool copy on a side stream)
+    #        -> wait for the returned event (a worker thread, bounded: ``wait_event``)
+    #        -> finish (engine thread: publish) or abort (engine thread: drop the reservation)
+    def commit_begin(self, hashes: list[int], pages: list[int], landed: bool = False, rccl: bool = False):
+        """Returns the event that says the bytes are in the pool pages (None: they already are)."""
         pool = self.engine.runner.pool
-        if any(self.reserved.get(h) != p for h, p in zip(hashes, pages)):
+        if len(hashes) != len(pages) or any(self.reserved.get(h) != p for h, p in zip(hashes, pages)):
             raise ValueError("commit of pages that are not reserved (the reservation expired?)")
-        slots = [self._slot_of.pop(h, None) for h in hashes]
         if landed:
+            slots = [self._slot_of.get(h) for h in hashes]
             if any(s is None for s in slots):
                 raise ValueError("commit of landed pages without landing slots")
             n = len(pages)
             sp = (ctypes.c_int64 * n)(*slots)
             dp = (ctypes.c_int64 * n)(*pages)
+            if self._copy_stream is None and pool.is_cuda:
+                self._copy_stream = _new_stream(pool)
+            # the producer synchronised its copy stream before it sent the commit: the window
+            # holds the bytes; the pool pages are reserved, nothing else touches them
             rc = comm().comm_push_pages(c_void_p(self._landing), c_void_p(pool.data_ptr()),
                                         pool.stride(0) * pool.element_size(), sp, dp, n,
-                                        c_void_p(torch.cuda.current_stream(pool.device).cuda_stream))
+                                        _stream_ptr(self._copy_stream))
             if rc != 0:
                 raise RuntimeError(f"landing window copy failed ({rc})")
-        if self.engine.runner.device.type == "cuda":
-            torch.cuda.synchronize()
-        self._free_slots.extend(s for s in slots if s is not None)
+            return _record(self._copy_stream)
+        if rccl:
+            return self._rccl_event
+        return None
+
+    def commit_finish(self, hashes: list[int], pages: list[int]) -> dict:
+        bm = self.engine.bm
+        if any(self.reserved.get(h) != p for h, p in zip(hashes, pages)):
+            raise ValueError("commit of pages that are not reserved (the reservation expired?)")
         for h, p in zip(hashes, pages):
+            slot = self._slot_of.pop(h, None)
+            if slot is not None:
+                self._free_slots.append(slot)
             self.reserved.pop(h, None)
             self._reserved_at.pop(h, None)
             bm.register(p, h)
         bm.free(pages)  # published pages wait in the prefix cache (evictable, LRU)
         return {"ok": True, "published": len(pages)}
+
+    def commit_abort(self, hashes: list[int]) -> None:
+        """The bytes never arrived (dead sender): give pages and slots back unpublished."""
+        for h in hashes:
+            self._reserved_at.pop(h, None)
+            page = self.reserved.pop(h, None)
+            if page is not None:
+                self.engine.bm.free([page])
+            slot = self._slot_of.pop(h, None)
+            if slot is not None:
+                self._free_slots.append(slot)
+
+    def commit(self, hashes: list[int], pages: list[int], landed: bool = False, rccl: bool = False) -> dict:
+        """All three stages on the calling thread (same-process transfers and tests; the HTTP
+        handler runs the wait on a worker thread instead)."""
+        ev = self.commit_begin(hashes, pages, landed, rccl)
+        if ev is not None and not wait_event(ev, 20.0):
+            self.commit_abort(hashes)
+            raise TimeoutError("transferred KV pages did not arrive within 20 s")
+        return self.commit_finish(hashes, pages)
 
 
 def local_push(src_engine, receiver: "KVReceiver", prompt_ids: list[int], window: bool = False) -> int:
@@ -477,18 +716,20 @@ def local_push(src_engine, receiver: "KVReceiver", prompt_ids: list[int], window
             landed = res.get("ipc_slots") is not None
             if window and not landed:
                 raise RuntimeError("the receiver offered no landing window")
-            if spool.is_cuda:
+            if _on_device(spool):
                 n = len(src)
                 sp = (ctypes.c_int64 * n)(*src)
                 dp = (ctypes.c_int64 * n)(*(res["ipc_slots"] if landed else dst))
                 base = receiver._landing if landed else dpool.data_ptr()
-                stream = torch.cuda.Stream(device=spool.device)
-                stream.wait_stream(torch.cuda.current_stream(spool.device))
+                stream = _new_stream(spool)
+                if stream is not None:
+                    stream.wait_stream(torch.cuda.current_stream(spool.device))
                 rc = comm().comm_push_pages(c_void_p(spool.data_ptr()), c_void_p(base),
-                                            page_bytes, sp, dp, n, c_void_p(stream.cuda_stream))
+                                            page_bytes, sp, dp, n, _stream_ptr(stream))
                 if rc != 0:
                     raise RuntimeError(f"comm_push_pages failed ({rc})")
-                stream.synchronize()
+                if stream is not None:
+                    stream.synchronize()
             else:
                 dpool[torch.tensor(dst)] = spool[torch.tensor(src)]
             receiver.commit(missing, dst, landed)
