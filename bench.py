@@ -4,9 +4,15 @@
 
 One engine replica per GPU (one process per GPU; for N > 1 the driver launches this file
 under ``torch.distributed.run`` and every rank hosts the replica of its GPU).  Rank 0 also
-starts the router (prefix-aware routing over the N replicas, static discovery) and the
-load-generator processes, which talk to the router over HTTP exactly like a client of a
-deployed stack.
+starts the router (prefix-aware routing over the N replicas, static discovery, several router
+worker processes from 4 replicas on) and the load-generator processes, which talk to the router
+over HTTP exactly like a client of a deployed stack.
+
+Every rank pins its process to its GPU with ``HIP_VISIBLE_DEVICES`` before anything touches the
+device, which is how the stack's own launcher (``vpsa-stack up``) and the chart place replicas:
+inside a replica the GPU is always device 0, whatever thread uses it.  Data-parallel replicas
+exchange nothing over the fabric, so the ranks synchronise (barriers, the max over ranks of the
+timed region) over gloo; RCCL comes in with tensor-parallel replicas and KV transfers, not here.
 
 Workload (reference: /root/reference/benchmarks/multi-round-qa/run.sh:14-18,43-48 and
 tutorials/08-benchmark-multi-round-qa-multi-gpu.md:36-72): users-per-GPU x N concurrent
@@ -20,6 +26,14 @@ prefill of every user and later rounds hit the KV cache.  Weak scaling: per-GPU 
 Prints one JSON line: value = aggregate output tokens/s over all GPUs (the throughput half
 of the headline metric); the TTFT half (p50/mean/p90, overall and warm-round) rides along
 in the same line.  Weights are random-init Llama-3-8B (bf16), prompts synthetic.
+
+After the timed headline region a second, short phase (``--reference-rounds``, default 3; not part
+of ``value``) runs the configuration the reference's own procedure prescribes
+(/root/reference/tutorials/07-benchmark-multi-round-qa-single-gpu.md:31-67): engine prefix
+caching off, chunked prefill off, KV offload to host DRAM on, ``session`` routing on
+``x-user-id``, 15 users per GPU.  Every follow-up turn then takes its 21k-token history from the
+pinned host pool over the side-stream copy engine; its tok/s, TTFT and tier counters are
+reported under ``reference_config`` in the same line.
 """
 
 from __future__ import annotations
@@ -47,7 +61,7 @@ def _default_base_port() -> int:
         mp = int(os.environ.get("MASTER_PORT", "0"))
     except ValueError:
         mp = 0
-    return 18100 + (mp % 500) * 20 if mp else 18100
+    return 18100 + (mp % 500) * 40 if mp else 18100
 
 
 def parse() -> argparse.Namespace:
@@ -64,11 +78,17 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--max-model-len", type=int, default=32000)
     ap.add_argument("--max-num-batched-tokens", type=int, default=8192)
     ap.add_argument("--routing-logic", default="prefixaware")
+    ap.add_argument("--router-workers", type=int, default=0, help="router processes (0 = 1 up to 3 replicas, "
+                                                                  "then one per two replicas, at most 4)")
     ap.add_argument("--cpu-offload-gb", type=float, default=0.0)
     ap.add_argument("--num-gpu-blocks", type=int, default=0,
                     help="cap the HBM KV pool (pages of 64 tokens) to exercise the host tier; 0 = size from HBM")
     ap.add_argument("--prefill-step-ms", type=float, default=30.0,
                     help="engine's latency-aware prefill admission target (0 = token budget only)")
+    ap.add_argument("--reference-rounds", type=int, default=3,
+                    help="rounds of the second phase in the reference's own configuration (0 = skip)")
+    ap.add_argument("--reference-users-per-gpu", type=int, default=15)
+    ap.add_argument("--reference-offload-gb", type=float, default=45.0)
     ap.add_argument("--base-port", type=int, default=_default_base_port())
     ap.add_argument("--clients", type=int, default=0, help="load-generator processes (0 = auto)")
     ap.add_argument("--device", default="cuda", help="cpu runs a plumbing rehearsal (tiny models)")
@@ -108,34 +128,52 @@ def client_main(a: argparse.Namespace) -> None:
 
 
 # ------------------------------------------------------------------ engine rank
-def spawn_children(a: argparse.Namespace, n: int):
-    """Router + load generators.  Called before this process touches the GPU."""
+def pin_gpu(a: argparse.Namespace) -> None:
+    """One process, one GPU: restrict this rank to its device before any GPU call.  With
+    ``VPSA_BENCH_SINGLE_DEVICE=1`` every rank takes the first device (a rehearsal of the N-rank
+    launch path on a one-GPU machine; the KV pools must then be capped with --num-gpu-blocks)."""
+    if a.device != "cuda" or os.environ.get("VPSA_BENCH_NO_PIN") == "1":
+        return
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("VPSA_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    visible = [x for x in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if x.strip()]
+    dev = visible[local_rank] if local_rank < len(visible) else str(local_rank)
+    os.environ["HIP_VISIBLE_DEVICES"] = dev
+    os.environ["VPSA_BENCH_PINNED_GPU"] = dev
+
+
+def spawn_children(a: argparse.Namespace, n: int, port0: int, routing: str, users_per_gpu: int,
+                   warm_users_per_gpu: int, rounds: int, warm_rounds: int, user_base: int):
+    """Router + load generators of one phase.  Never touches the GPU."""
     env = dict(os.environ)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "HIP_VISIBLE_DEVICES"):
         env.pop(k, None)
-    backends = ",".join(f"http://127.0.0.1:{a.base_port + 1 + r}" for r in range(n))
+    backends = ",".join(f"http://127.0.0.1:{port0 + 1 + r}" for r in range(n))
+    workers = a.router_workers or (1 if n < 4 else min(4, n // 2))
     router_cmd = [sys.executable, "-m", "vllm_production_stack_amd.router.app",
-                  "--host", "127.0.0.1", "--port", str(a.base_port),
+                  "--host", "127.0.0.1", "--port", str(port0),
                   "--service-discovery", "static", "--static-backends", backends,
                   "--static-models", ",".join([a.model] * n),
-                  "--routing-logic", a.routing_logic, "--session-key", "x-user-id",
+                  "--routing-logic", routing, "--session-key", "x-user-id",
+                  "--router-workers", str(workers),
                   "--engine-stats-interval", "5", "--log-level", "warning"]
     router = subprocess.Popen(router_cmd, env=env, cwd=ROOT)
     n_clients = a.clients or max(1, min(4, (n + 1) // 2))
-    users = list(range(a.users_per_gpu * n))
-    wusers = list(range(10_000_000, 10_000_000 + a.warmup_users_per_gpu * n))
+    users = list(range(user_base, user_base + users_per_gpu * n))
+    wusers = list(range(user_base + 10_000_000, user_base + 10_000_000 + warm_users_per_gpu * n))
     clients = []
     for c in range(n_clients):
         cmd = [sys.executable, os.path.abspath(__file__), "--client",
-               "--base-url", f"http://127.0.0.1:{a.base_port}", "--model", a.model,
-               "--steps", str(a.steps), "--warmup", str(a.warmup),
+               "--base-url", f"http://127.0.0.1:{port0}", "--model", a.model,
+               "--steps", str(rounds), "--warmup", str(warm_rounds),
                "--sys-len", str(a.sys_len), "--history-len", str(a.history_len),
                "--answer-len", str(a.answer_len),
                "--user-ids", ",".join(map(str, users[c::n_clients])),
                "--warmup-user-ids", ",".join(map(str, wusers[c::n_clients]))]
         clients.append(subprocess.Popen(cmd, env=env, cwd=ROOT, stdin=subprocess.PIPE,
                                         stdout=subprocess.PIPE, text=True, bufsize=1))
-    return router, clients
+    return router, clients, workers
 
 
 def wait_line(p: subprocess.Popen, prefix: str) -> str:
@@ -147,54 +185,51 @@ def wait_line(p: subprocess.Popen, prefix: str) -> str:
             return line[len(prefix):].strip()
 
 
-async def rank_main(a: argparse.Namespace) -> None:
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n = max(a.gpus, world)
-    router, clients = spawn_children(a, n) if rank == 0 else (None, [])
-    procs = ([router] if router else []) + clients
+def stop_children(procs) -> None:
+    for p in procs:
+        try:
+            p.terminate()
+        except Exception:
+            pass
+    for p in procs:
+        try:
+            p.wait(timeout=10)
+        except Exception:
+            p.kill()
 
+
+async def run_phase(a, ctx, *, port0: int, routing: str, users_per_gpu: int, warm_users_per_gpu: int,
+                    rounds: int, warm_rounds: int, user_base: int, engine_kwargs: dict) -> dict | None:
+    """One measured phase: engine up, children up, warm-up, the timed rounds, everything down again
+    (router and load generators first, so nothing scrapes an engine that is already gone).
+    Returns the result dictionary on rank 0."""
     import torch
     import torch.distributed as dist
 
     from vllm_production_stack_amd.engine.async_engine import AsyncLLMEngine
-    from vllm_production_stack_amd.engine.config import EngineConfig, KVOffloadConfig
+    from vllm_production_stack_amd.engine.config import EngineConfig
     from vllm_production_stack_amd.engine.llm_engine import LLMEngine
     from vllm_production_stack_amd.engine.server import serve
 
-    try:
-        on_gpu = a.device == "cuda"
-        gloo = None
+    rank, world, n, on_gpu, gloo = ctx["rank"], ctx["world"], ctx["n"], ctx["on_gpu"], ctx["gloo"]
+    router, clients, workers, procs = None, [], 0, []
+    engine = ae = runner = None
+
+    def barrier():
         if on_gpu:
-            torch.cuda.set_device(local_rank)
-        if world > 1:
-            if on_gpu:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-                gloo = dist.new_group(backend="gloo")
-                dist.barrier()  # brings RCCL up over xGMI before serving starts
-            else:
-                dist.init_process_group("gloo")
-                gloo = dist.group.WORLD
+            torch.cuda.synchronize()
+        if gloo is not None:
+            dist.barrier(group=gloo)
+        if on_gpu:
+            torch.cuda.synchronize()
 
-        def barrier():
-            if on_gpu:
-                torch.cuda.synchronize()
-            if gloo is not None:
-                dist.barrier(group=gloo)
-            if on_gpu:
-                torch.cuda.synchronize()
-
-        loop = asyncio.get_running_loop()
-        off = KVOffloadConfig(local_cpu=a.cpu_offload_gb > 0, max_local_cpu_gb=a.cpu_offload_gb)
+    loop = asyncio.get_running_loop()
+    try:
         cfg = EngineConfig(model=a.model, served_model_name=a.model, host="127.0.0.1",
                            device="auto" if on_gpu else "cpu",
                            dtype="auto" if on_gpu else "float32",
-                           port=a.base_port + 1 + rank, max_model_len=a.max_model_len,
-                           max_num_seqs=256, max_num_batched_tokens=a.max_num_batched_tokens,
-                           enable_prefix_caching=True, enable_chunked_prefill=True, kv_offload=off,
-                           num_gpu_blocks_override=a.num_gpu_blocks or None,
-                           prefill_step_ms=a.prefill_step_ms)
+                           port=port0 + 1 + rank, max_model_len=a.max_model_len, max_num_seqs=256,
+                           num_gpu_blocks_override=a.num_gpu_blocks or None, **engine_kwargs)
         engine = LLMEngine(cfg)
         ae = AsyncLLMEngine(engine)
         ae.start(loop)
@@ -204,10 +239,15 @@ async def rank_main(a: argparse.Namespace) -> None:
         if rank == 0:
             import aiohttp
 
+            # only now: a router that starts before its backends logs a failed scrape for each
+            router, clients, workers = spawn_children(a, n, port0, routing, users_per_gpu, warm_users_per_gpu,
+                                                      rounds, warm_rounds, user_base)
+            procs.extend([router] + clients)
+
             async with aiohttp.ClientSession() as s:
                 for _ in range(300):
                     try:
-                        async with s.get(f"http://127.0.0.1:{a.base_port}/health") as r:
+                        async with s.get(f"http://127.0.0.1:{port0}/health") as r:
                             if r.status == 200:
                                 break
                     except aiohttp.ClientError:
@@ -221,6 +261,7 @@ async def rank_main(a: argparse.Namespace) -> None:
             for p in clients:
                 await loop.run_in_executor(None, wait_line, p, "READY")  # warm-up rounds done
 
+        prof0 = dict(engine.prof)
         await loop.run_in_executor(None, barrier)
         t_start = time.time()
         outs = []
@@ -233,8 +274,13 @@ async def rank_main(a: argparse.Namespace) -> None:
         await loop.run_in_executor(None, barrier)
         elapsed = time.time() - t_start
         # what every replica did in the timed region (shows how evenly the router spread the users)
-        mine = {"rank": rank, "steps": int(engine.prof["steps"]), "busy_s": round(float(engine.prof["t_execute"]), 2),
-                "rows": int(engine.prof["rows"])}
+        mine = {"rank": rank, "steps": int(engine.prof["steps"] - prof0["steps"]),
+                "busy_s": round(float(engine.prof["t_execute"] - prof0["t_execute"]), 2),
+                "rows": int(engine.prof["rows"] - prof0["rows"]), "gpu": os.environ.get("VPSA_BENCH_PINNED_GPU")}
+        conn = engine.connector
+        if conn is not None and conn.host is not None:
+            mine["host_loads_pages"] = conn.host.loads
+            mine["host_stores_pages"] = conn.host.stores
         per_replica = [mine]
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64)
@@ -242,66 +288,158 @@ async def rank_main(a: argparse.Namespace) -> None:
             elapsed = float(t.item())
             per_replica = [None] * world
             dist.all_gather_object(per_replica, mine, group=gloo)
+        if rank != 0:
+            return None
 
+        sys.path.insert(0, os.path.join(ROOT, "benchmarks", "multi_round_qa"))
+        import multi_round_qa as mrq
+
+        rows = [r for o in outs for r in o["rows"]]
+        bad = [r for r in rows if r["ttft"] < 0]
+        ttfts = [r["ttft"] for r in rows if r["ttft"] >= 0]
+        warm = [r["ttft"] for r in rows if r["ttft"] >= 0 and r["question_id"] > 1]
+        cold = [r["ttft"] for r in rows if r["ttft"] >= 0 and r["question_id"] == 1]
+        out_tokens = sum(r["generation_tokens"] for r in rows)
+        in_tokens = sum(r["prompt_tokens"] for r in rows)
+        return {
+            "elapsed_s": round(elapsed, 3), "out_tokens": out_tokens, "in_tokens": in_tokens,
+            "tok_per_s": round(out_tokens / elapsed, 2), "requests": len(rows), "failed_requests": len(bad),
+            "p50_ttft_s": round(mrq.pct(ttfts, 0.5), 4) if ttfts else None,
+            "mean_ttft_s": round(sum(ttfts) / max(1, len(ttfts)), 4),
+            "p90_ttft_s": round(mrq.pct(ttfts, 0.9), 4) if ttfts else None,
+            "p50_ttft_warm_rounds_s": round(mrq.pct(warm, 0.5), 4) if warm else None,
+            "p50_ttft_cold_round_s": round(mrq.pct(cold, 0.5), 4) if cold else None,
+            "round_times_s": [round(x, 3) for x in outs[0]["round_times"]] if outs else [],
+            "per_replica": per_replica, "router_workers": workers,
+            "kv_pages_per_replica": engine.runner.num_pages,
+            "kv_tiers": ({"host_loads_pages": conn.host.loads, "host_stores_pages": conn.host.stores,
+                          "host_evictions_pages": conn.host.evictions, "host_slots": conn.host.n_slots}
+                         if conn is not None and conn.host is not None else None),
+            "engine0_profile": {k: (round(v - prof0.get(k, 0), 3) if isinstance(v, float) else v - prof0.get(k, 0))
+                                for k, v in engine.prof.items()},
+        }
+    finally:
+        # order matters for a clean log: the router (rank 0) goes first, every rank waits for that,
+        # and only then do the engines stop answering its metric scrapes
+        stop_children(procs)
+        if gloo is not None:
+            try:
+                import datetime
+
+                dist.monitored_barrier(group=gloo, timeout=datetime.timedelta(seconds=30))
+            except Exception:
+                pass
+        if runner is not None:
+            await runner.cleanup()
+        if ae is not None:
+            ae.stop()
+
+
+def release_gpu_memory() -> None:
+    """Between phases: the previous engine's weights, KV pool and graphs are unreachable once
+    ``run_phase`` has returned; collect them and hand the blocks back to the driver."""
+    import gc
+
+    import torch
+
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+
+async def rank_main(a: argparse.Namespace) -> None:
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n = max(a.gpus, world)
+    pin_gpu(a)
+    # stdout carries the one JSON line and nothing else: libraries that chat on file descriptor 1
+    # (gloo announces its connections there) are sent to stderr
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    import torch
+    import torch.distributed as dist
+
+    from vllm_production_stack_amd.engine.config import KVOffloadConfig
+
+    on_gpu = a.device == "cuda"
+    gloo = None
+    if on_gpu:
+        torch.cuda.set_device(0 if os.environ.get("VPSA_BENCH_PINNED_GPU") is not None
+                              else int(os.environ.get("LOCAL_RANK", "0")))
+    if world > 1:
+        dist.init_process_group("gloo")
+        gloo = dist.group.WORLD
+    ctx = {"rank": rank, "world": world, "n": n, "on_gpu": on_gpu, "gloo": gloo}
+    try:
+        off = KVOffloadConfig(local_cpu=a.cpu_offload_gb > 0, max_local_cpu_gb=a.cpu_offload_gb)
+        head = await run_phase(
+            a, ctx, port0=a.base_port, routing=a.routing_logic, users_per_gpu=a.users_per_gpu,
+            warm_users_per_gpu=a.warmup_users_per_gpu, rounds=a.steps, warm_rounds=a.warmup, user_base=0,
+            engine_kwargs=dict(max_num_batched_tokens=a.max_num_batched_tokens, enable_prefix_caching=True,
+                               enable_chunked_prefill=True, kv_offload=off, prefill_step_ms=a.prefill_step_ms))
+        ref = None
+        if a.reference_rounds > 0:
+            release_gpu_memory()
+            try:
+                ref = await run_phase(
+                    a, ctx, port0=a.base_port + 20, routing="session", users_per_gpu=a.reference_users_per_gpu,
+                    warm_users_per_gpu=1, rounds=a.reference_rounds, warm_rounds=1, user_base=20_000_000,
+                    engine_kwargs=dict(max_num_batched_tokens=max(a.max_num_batched_tokens, a.max_model_len),
+                                       enable_prefix_caching=False, enable_chunked_prefill=False,
+                                       prefill_step_ms=0.0,
+                                       kv_offload=KVOffloadConfig(local_cpu=True,
+                                                                  max_local_cpu_gb=a.reference_offload_gb)))
+            except Exception as e:  # the headline result stands on its own
+                ref = {"error": repr(e)} if rank == 0 else None
         if rank == 0:
-            sys.path.insert(0, os.path.join(ROOT, "benchmarks", "multi_round_qa"))
-            import multi_round_qa as mrq
-
-            rows = [r for o in outs for r in o["rows"]]
-            bad = [r for r in rows if r["ttft"] < 0]
-            out_tokens = sum(r["generation_tokens"] for r in rows)
-            in_tokens = sum(r["prompt_tokens"] for r in rows)
-            ttfts = [r["ttft"] for r in rows if r["ttft"] >= 0]
-            warm = [r["ttft"] for r in rows if r["ttft"] >= 0 and r["question_id"] > 1]
-            cold = [r["ttft"] for r in rows if r["ttft"] >= 0 and r["question_id"] == 1]
             users_total = a.users_per_gpu * n
             model_label = "Llama-3-8B" if a.model == "llama-3-8b" else a.model
             result = {
                 "metric": f"output tok/s (+ p50 TTFT), multi-round QA, {model_label}, router + N engine replicas",
-                "value": round(out_tokens / elapsed, 2), "unit": "tokens/s", "n_gpus": n,
+                "value": head["tok_per_s"], "unit": "tokens/s", "n_gpus": n,
                 "steps": a.steps, "warmup": a.warmup,
-                "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True,
+                "ms_per_step": round(head["elapsed_s"] / a.steps * 1e3, 2), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if on_gpu else "fp32",
                 "data": f"synthetic multi-turn prompts; random-init {model_label} weights",
-                "p50_ttft_s": round(mrq.pct(ttfts, 0.5), 4),
-                "mean_ttft_s": round(sum(ttfts) / max(1, len(ttfts)), 4),
-                "p90_ttft_s": round(mrq.pct(ttfts, 0.9), 4),
-                "p50_ttft_warm_rounds_s": round(mrq.pct(warm, 0.5), 4) if warm else None,
-                "p50_ttft_cold_round_s": round(mrq.pct(cold, 0.5), 4) if cold else None,
-                "input_tok_per_s": round(in_tokens / elapsed, 1), "requests": len(rows),
-                "failed_requests": len(bad), "elapsed_s": round(elapsed, 3),
-                "round_times_s": [round(x, 3) for x in outs[0]["round_times"]] if outs else [],
+                "p50_ttft_s": head["p50_ttft_s"], "mean_ttft_s": head["mean_ttft_s"],
+                "p90_ttft_s": head["p90_ttft_s"],
+                "p50_ttft_warm_rounds_s": head["p50_ttft_warm_rounds_s"],
+                "p50_ttft_cold_round_s": head["p50_ttft_cold_round_s"],
+                "input_tok_per_s": round(head["in_tokens"] / head["elapsed_s"], 1),
+                "requests": head["requests"], "failed_requests": head["failed_requests"],
+                "elapsed_s": head["elapsed_s"], "round_times_s": head["round_times_s"],
                 "config": {"model": model_label, "global_batch": users_total,
                            "seq_len": a.sys_len + a.history_len, "answer_len": a.answer_len,
                            "rounds": a.steps, "parallelism": f"dp{n} (replicas behind router)",
-                           "routing": a.routing_logic,
-                           "kv_pages_per_replica": engine.runner.num_pages,
-                           "cpu_offload_gb": a.cpu_offload_gb,
-                           "prefill_step_ms": a.prefill_step_ms},
-                "kv_tiers": ({"host_loads_pages": engine.connector.host.loads,
-                              "host_stores_pages": engine.connector.host.stores,
-                              "host_evictions_pages": engine.connector.host.evictions}
-                             if engine.connector is not None and engine.connector.host is not None else None),
-                "engine0_profile": {k: (round(v, 3) if isinstance(v, float) else v)
-                                    for k, v in engine.prof.items()},
-                "per_replica": per_replica,
+                           "routing": a.routing_logic, "router_workers": head["router_workers"],
+                           "kv_pages_per_replica": head["kv_pages_per_replica"],
+                           "cpu_offload_gb": a.cpu_offload_gb, "prefill_step_ms": a.prefill_step_ms},
+                "kv_tiers": head["kv_tiers"], "engine0_profile": head["engine0_profile"],
+                "per_replica": head["per_replica"],
             }
-            print(json.dumps(result), flush=True)
-        await runner.cleanup()
-        ae.stop()
+            if ref is not None:
+                if "error" in ref:
+                    result["reference_config"] = ref
+                else:
+                    result["reference_config"] = {
+                        "what": "second phase, not part of value: engine prefix caching off, chunked prefill "
+                                "off, KV offload to pinned host DRAM on, session routing on x-user-id "
+                                "(the reference's own benchmark setup)",
+                        "users": a.reference_users_per_gpu * n, "rounds": a.reference_rounds,
+                        "cpu_offload_gb_per_replica": a.reference_offload_gb,
+                        "output_tok_per_s": ref["tok_per_s"], "p50_ttft_s": ref["p50_ttft_s"],
+                        "p50_ttft_warm_rounds_s": ref["p50_ttft_warm_rounds_s"],
+                        "p50_ttft_cold_round_s": ref["p50_ttft_cold_round_s"],
+                        "round_times_s": ref["round_times_s"], "requests": ref["requests"],
+                        "failed_requests": ref["failed_requests"], "kv_tiers": ref["kv_tiers"],
+                        "per_replica": ref["per_replica"]}
+            print(json.dumps(result), file=result_out, flush=True)
+    finally:
         if world > 1:
             dist.destroy_process_group()
-    finally:
-        for p in procs:
-            try:
-                p.terminate()
-            except Exception:
-                pass
-        for p in procs:
-            try:
-                p.wait(timeout=10)
-            except Exception:
-                p.kill()
 
 
 def main() -> None:
@@ -313,7 +451,7 @@ def main() -> None:
         # direct invocation with N > 1: relaunch under torchrun, one rank per GPU
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port",
-               str(a.base_port + 50), os.path.abspath(__file__)] + sys.argv[1:]
+               str(a.base_port + 39), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
     asyncio.run(rank_main(a))
 

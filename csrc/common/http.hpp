@@ -34,22 +34,52 @@ inline std::string lower(std::string s) {
   return s;
 }
 
+// Limits of what a peer may make this process buffer.
+constexpr size_t kMaxHeaderBytes = 1u << 20;
+constexpr size_t kMaxBodyBytes = 64u << 20;
+
+// Value of a header in a lower-cased head block ("" when absent).  Only a name at the start of a
+// line counts: "x-content-length: 9" or a value that mentions the name must not match.
+inline std::string header_value(const std::string& lower_head, const std::string& name) {
+  size_t pos = 0;
+  const std::string needle = "\r\n" + name + ":";
+  size_t p = lower_head.find(needle, pos);
+  if (p == std::string::npos) return "";
+  size_t b = p + needle.size(), e = lower_head.find("\r\n", b);
+  std::string v = lower_head.substr(b, e == std::string::npos ? std::string::npos : e - b);
+  while (!v.empty() && (v[0] == ' ' || v[0] == '\t')) v.erase(0, 1);
+  while (!v.empty() && (v.back() == ' ' || v.back() == '\t')) v.pop_back();
+  return v;
+}
+
+// Content-Length of a head block: -1 when absent, -2 when present but not a plain decimal number
+// or larger than the body limit.
+inline long long content_length(const std::string& lower_head) {
+  std::string v = header_value(lower_head, "content-length");
+  if (v.empty()) return lower_head.find("\r\ncontent-length:") == std::string::npos ? -1 : -2;
+  if (v.size() > 12) return -2;
+  for (char c : v)
+    if (c < '0' || c > '9') return -2;
+  long long n = atoll(v.c_str());
+  return n > (long long)kMaxBodyBytes ? -2 : n;
+}
+
+// Reads one request (head + Content-Length body) from fd.  false = connection closed, a read
+// error, or a message this server refuses to buffer (oversized head or body, bad length).
 inline bool read_message(int fd, std::string& buf, std::string& head, std::string& body) {
   size_t hdr_end;
   while ((hdr_end = buf.find("\r\n\r\n")) == std::string::npos) {
+    if (buf.size() > kMaxHeaderBytes) return false;
     char tmp[8192];
     ssize_t n = recv(fd, tmp, sizeof tmp, 0);
     if (n <= 0) return false;
     buf.append(tmp, (size_t)n);
-    if (buf.size() > (64u << 20)) return false;
   }
+  if (hdr_end > kMaxHeaderBytes) return false;
   head = buf.substr(0, hdr_end);
-  size_t clen = 0;
-  {
-    std::string lh = lower(head);
-    size_t p = lh.find("content-length:");
-    if (p != std::string::npos) clen = (size_t)strtoull(lh.c_str() + p + 15, nullptr, 10);
-  }
+  long long cl = content_length(lower(head));
+  if (cl == -2) return false;
+  size_t clen = cl < 0 ? 0 : (size_t)cl;
   size_t need = hdr_end + 4 + clen;
   while (buf.size() < need) {
     char tmp[65536];
@@ -62,12 +92,17 @@ inline bool read_message(int fd, std::string& buf, std::string& head, std::strin
   return true;
 }
 
-inline void parse_head(const std::string& head, Request& r) {
+// false when the request line is not "METHOD SP target SP HTTP/x.y".
+inline bool parse_head(const std::string& head, Request& r) {
   size_t eol = head.find("\r\n");
   std::string line = head.substr(0, eol);
   size_t a = line.find(' '), b = line.rfind(' ');
+  if (a == std::string::npos || b == a || a == 0 || line.compare(b + 1, 5, "HTTP/") != 0) return false;
   r.method = line.substr(0, a);
+  for (char c : r.method)
+    if (c < 'A' || c > 'Z') return false;
   std::string target = line.substr(a + 1, b - a - 1);
+  if (target.empty() || target[0] != '/') return false;
   size_t q = target.find('?');
   r.path = target.substr(0, q);
   r.query = q == std::string::npos ? "" : target.substr(q + 1);
@@ -84,6 +119,7 @@ inline void parse_head(const std::string& head, Request& r) {
     }
     pos = e + 2;
   }
+  return true;
 }
 
 inline std::string query_param(const std::string& query, const std::string& key) {
@@ -150,14 +186,19 @@ class Server {
     std::string buf, head, body;
     while (read_message(c, buf, head, body)) {
       Request r;
-      parse_head(head, r);
-      r.body = std::move(body);
       Response resp;
-      try {
-        resp = handler_(r);
-      } catch (const std::exception& e) {
-        resp.status = 500;
-        resp.body = std::string("{\"error\":\"") + e.what() + "\"}";
+      if (!parse_head(head, r)) {
+        resp.status = 400;
+        resp.body = "{\"error\":\"malformed request line\"}";
+      } else {
+        r.body = std::move(body);
+        try {
+          resp = handler_(r);
+        } catch (const std::exception& e) {
+          resp.status = 500;
+          resp.body = "{\"error\":\"internal error\"}";
+          (void)e;
+        }
       }
       std::string out = "HTTP/1.1 " + std::to_string(resp.status) + " X\r\nContent-Type: " +
                         resp.content_type + "\r\nContent-Length: " + std::to_string(resp.body.size()) +
@@ -180,10 +221,8 @@ class Server {
   std::thread acceptor_;
 };
 
-// url = http://host:port[/prefix]; returns status (0 on connection failure)
-inline int request(const std::string& method, const std::string& url, const std::string& path,
-                   const std::string& body, std::string* out, const std::string& content_type = "application/json",
-                   const std::string& bearer = "") {
+// Splits http://host:port[/prefix] and connects; returns the socket (-1 on failure).
+inline int connect_url(const std::string& url, std::string* host_out, std::string* prefix_out, int timeout_s) {
   std::string rest = url.substr(url.find("://") == std::string::npos ? 0 : url.find("://") + 3);
   std::string prefix;
   size_t slash = rest.find('/');
@@ -201,55 +240,166 @@ inline int request(const std::string& method, const std::string& url, const std:
   addrinfo hints{}, *res = nullptr;
   hints.ai_family = AF_UNSPEC;
   hints.ai_socktype = SOCK_STREAM;
-  if (getaddrinfo(host.c_str(), port.c_str(), &hints, &res) != 0 || !res) return 0;
+  if (getaddrinfo(host.c_str(), port.c_str(), &hints, &res) != 0 || !res) return -1;
   int fd = socket(res->ai_family, res->ai_socktype, res->ai_protocol);
-  timeval tv{10, 0};
-  setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
-  setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
-  if (fd < 0 || connect(fd, res->ai_addr, res->ai_addrlen) != 0) {
-    if (fd >= 0) close(fd);
-    freeaddrinfo(res);
-    return 0;
+  if (fd >= 0) {
+    timeval tv{timeout_s, 0};
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+    setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+    if (connect(fd, res->ai_addr, res->ai_addrlen) != 0) {
+      close(fd);
+      fd = -1;
+    }
   }
   freeaddrinfo(res);
+  if (host_out) *host_out = host;
+  if (prefix_out) *prefix_out = prefix;
+  return fd;
+}
+
+inline bool send_all(int fd, const std::string& data) {
+  size_t off = 0;
+  while (off < data.size()) {
+    ssize_t n = send(fd, data.data() + off, data.size() - off, MSG_NOSIGNAL);
+    if (n <= 0) return false;
+    off += (size_t)n;
+  }
+  return true;
+}
+
+// Decodes a chunked body held completely in `payload`; stops at the first malformed chunk header
+// or at a chunk that claims more bytes than there are.
+inline std::string dechunk(const std::string& payload) {
+  std::string dec;
+  size_t p = 0;
+  while (p < payload.size()) {
+    size_t e = payload.find("\r\n", p);
+    if (e == std::string::npos || e == p || e - p > 16) break;
+    char* endp = nullptr;
+    std::string hex = payload.substr(p, e - p);
+    unsigned long long len = strtoull(hex.c_str(), &endp, 16);
+    if (endp == hex.c_str() || len == 0) break;
+    if (len > payload.size() - (e + 2)) {
+      dec.append(payload, e + 2, std::string::npos);
+      break;
+    }
+    dec.append(payload, e + 2, (size_t)len);
+    p = e + 2 + (size_t)len + 2;
+  }
+  return dec;
+}
+
+// url = http://host:port[/prefix]; returns status (0 on connection failure)
+inline int request(const std::string& method, const std::string& url, const std::string& path,
+                   const std::string& body, std::string* out, const std::string& content_type = "application/json",
+                   const std::string& bearer = "") {
+  std::string host, prefix;
+  int fd = connect_url(url, &host, &prefix, 10);
+  if (fd < 0) return 0;
   std::string req = method + " " + prefix + path + " HTTP/1.1\r\nHost: " + host + "\r\nConnection: close\r\n";
   if (!bearer.empty()) req += "Authorization: Bearer " + bearer + "\r\n";
   if (!body.empty() || method == "POST" || method == "PUT" || method == "PATCH")
     req += "Content-Type: " + content_type + "\r\nContent-Length: " + std::to_string(body.size()) + "\r\n";
   req += "\r\n" + body;
-  size_t off = 0;
-  while (off < req.size()) {
-    ssize_t n = send(fd, req.data() + off, req.size() - off, MSG_NOSIGNAL);
-    if (n <= 0) {
-      close(fd);
-      return 0;
-    }
-    off += (size_t)n;
+  if (!send_all(fd, req)) {
+    close(fd);
+    return 0;
   }
   std::string resp;
   char tmp[65536];
   ssize_t n;
-  while ((n = recv(fd, tmp, sizeof tmp, 0)) > 0) resp.append(tmp, (size_t)n);
+  while ((n = recv(fd, tmp, sizeof tmp, 0)) > 0) {
+    resp.append(tmp, (size_t)n);
+    if (resp.size() > kMaxBodyBytes + kMaxHeaderBytes) break;
+  }
   close(fd);
   size_t he = resp.find("\r\n\r\n");
-  if (he == std::string::npos || resp.size() < 12) return 0;
+  if (he == std::string::npos || resp.size() < 12 || resp.compare(0, 5, "HTTP/") != 0) return 0;
   int status = atoi(resp.c_str() + 9);
   std::string head = lower(resp.substr(0, he));
   std::string payload = resp.substr(he + 4);
-  if (head.find("transfer-encoding: chunked") != std::string::npos) {
-    std::string dec;
-    size_t p = 0;
-    while (p < payload.size()) {
-      size_t e = payload.find("\r\n", p);
-      if (e == std::string::npos) break;
-      size_t len = strtoul(payload.substr(p, e - p).c_str(), nullptr, 16);
-      if (len == 0) break;
-      dec.append(payload, e + 2, len);
-      p = e + 2 + len + 2;
-    }
-    payload.swap(dec);
-  }
+  if (header_value(head, "transfer-encoding").find("chunked") != std::string::npos) payload = dechunk(payload);
   if (out) *out = std::move(payload);
+  return status;
+}
+
+// GET whose body is consumed line by line while it arrives (a Kubernetes watch: one JSON event
+// per line, chunked, open for minutes).  `on_line` returns false to hang up.  Returns the HTTP
+// status (0: could not connect / no valid response head); the call ends when the server closes
+// the stream, `idle_timeout_s` passes without a byte, or a line exceeds the body limit.
+inline int stream_lines(const std::string& url, const std::string& path, const std::string& bearer,
+                        const std::function<bool(const std::string&)>& on_line, int idle_timeout_s = 60) {
+  std::string host, prefix;
+  int fd = connect_url(url, &host, &prefix, idle_timeout_s);
+  if (fd < 0) return 0;
+  std::string req = "GET " + prefix + path + " HTTP/1.1\r\nHost: " + host + "\r\nConnection: close\r\nAccept: application/json\r\n";
+  if (!bearer.empty()) req += "Authorization: Bearer " + bearer + "\r\n";
+  req += "\r\n";
+  if (!send_all(fd, req)) {
+    close(fd);
+    return 0;
+  }
+  std::string buf;
+  char tmp[16384];
+  size_t he;
+  while ((he = buf.find("\r\n\r\n")) == std::string::npos) {
+    ssize_t n = recv(fd, tmp, sizeof tmp, 0);
+    if (n <= 0 || buf.size() > kMaxHeaderBytes) {
+      close(fd);
+      return 0;
+    }
+    buf.append(tmp, (size_t)n);
+  }
+  if (buf.compare(0, 5, "HTTP/") != 0 || buf.size() < 12) {
+    close(fd);
+    return 0;
+  }
+  int status = atoi(buf.c_str() + 9);
+  bool chunked = header_value(lower(buf.substr(0, he)), "transfer-encoding").find("chunked") != std::string::npos;
+  std::string raw = buf.substr(he + 4), data;  // raw: undecoded bytes, data: decoded bytes not yet split
+  bool go = status == 200, eof = false;
+  while (go) {
+    if (chunked) {
+      // move every complete chunk from raw to data
+      for (;;) {
+        size_t e = raw.find("\r\n");
+        if (e == std::string::npos) break;
+        if (e == 0 || e > 16) {
+          go = false;
+          break;
+        }
+        char* endp = nullptr;
+        std::string hex = raw.substr(0, e);
+        unsigned long long len = strtoull(hex.c_str(), &endp, 16);
+        if (endp == hex.c_str() || len > kMaxBodyBytes) {
+          go = false;
+          break;
+        }
+        if (len == 0) {
+          eof = true;
+          break;
+        }
+        if (raw.size() < e + 2 + len + 2) break;
+        data.append(raw, e + 2, (size_t)len);
+        raw.erase(0, e + 2 + (size_t)len + 2);
+      }
+    } else {
+      data += raw;
+      raw.clear();
+    }
+    size_t nl;
+    while (go && (nl = data.find('\n')) != std::string::npos) {
+      std::string line = data.substr(0, nl);
+      data.erase(0, nl + 1);
+      if (!line.empty() && line.back() == '\r') line.pop_back();
+      if (!line.empty() && !on_line(line)) go = false;
+    }
+    if (!go || eof || data.size() > kMaxBodyBytes) break;
+    ssize_t n = recv(fd, tmp, sizeof tmp, 0);
+    if (n <= 0) break;
+    raw.append(tmp, (size_t)n);
+  }
+  close(fd);
   return status;
 }
 

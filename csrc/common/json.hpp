@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -83,6 +84,16 @@ struct Value {
     const Value& v = at(path);
     return v.type == Number ? v.num : def;
   }
+  // integer view of a number, clamped to [lo, hi]; `def` when missing, not a number or not finite
+  // (a double outside the target range must never reach an integer cast: that is undefined)
+  int64_t i(const std::string& path, int64_t def = 0, int64_t lo = -(int64_t(1) << 53),
+            int64_t hi = int64_t(1) << 53) const {
+    const Value& v = at(path);
+    if (v.type != Number || !std::isfinite(v.num)) return def;
+    if (v.num <= (double)lo) return lo;
+    if (v.num >= (double)hi) return hi;
+    return (int64_t)v.num;
+  }
   bool flag(const std::string& path, bool def = false) const {
     const Value& v = at(path);
     return v.type == Bool ? v.b : def;
@@ -139,7 +150,11 @@ inline void dump(const Value& v, std::string& out) {
     case Value::Bool: out += v.b ? "true" : "false"; break;
     case Value::Number: {
       char buf[32];
-      if (v.num == (double)(int64_t)v.num && v.num > -1e15 && v.num < 1e15)
+      if (!std::isfinite(v.num)) {  // JSON has no NaN / Infinity
+        out += "null";
+        break;
+      }
+      if (v.num > -1e15 && v.num < 1e15 && v.num == std::floor(v.num))
         snprintf(buf, sizeof buf, "%lld", (long long)v.num);
       else
         snprintf(buf, sizeof buf, "%.17g", v.num);
@@ -191,8 +206,17 @@ class Parser {
   }
 
  private:
+  // nesting deeper than this is refused: the parser recurses once per level, and a body of
+  // nothing but '[' would otherwise turn a 64 MiB request into a stack overflow
+  static constexpr int kMaxDepth = 192;
   const char* p_;
   const char* end_;
+  int depth_ = 0;
+  struct Nest {
+    int& d;
+    explicit Nest(int& depth) : d(depth) { ++d; }
+    ~Nest() { --d; }
+  };
   void ws() {
     while (p_ < end_ && (*p_ == ' ' || *p_ == '\n' || *p_ == '\t' || *p_ == '\r')) ++p_;
   }
@@ -210,10 +234,27 @@ class Parser {
     return number();
   }
   Value number() {
-    char* e = nullptr;
-    double d = strtod(p_, &e);
-    if (e == p_) fail("bad number");
-    p_ = e;
+    // JSON grammar only: strtod alone would also take "inf", "nan", hex floats and a leading '+'
+    const char* q = p_;
+    if (q < end_ && *q == '-') ++q;
+    if (q >= end_ || *q < '0' || *q > '9') fail("bad number");
+    while (q < end_ && *q >= '0' && *q <= '9') ++q;
+    if (q < end_ && *q == '.') {
+      ++q;
+      if (q >= end_ || *q < '0' || *q > '9') fail("bad number");
+      while (q < end_ && *q >= '0' && *q <= '9') ++q;
+    }
+    if (q < end_ && (*q == 'e' || *q == 'E')) {
+      ++q;
+      if (q < end_ && (*q == '+' || *q == '-')) ++q;
+      if (q >= end_ || *q < '0' || *q > '9') fail("bad number");
+      while (q < end_ && *q >= '0' && *q <= '9') ++q;
+    }
+    if (q - p_ > 400) fail("number too long");
+    std::string tok(p_, q);
+    double d = strtod(tok.c_str(), nullptr);
+    if (!std::isfinite(d)) d = d > 0 ? 1.7976931348623157e308 : -1.7976931348623157e308;
+    p_ = q;
     return Value(d);
   }
   static void utf8(unsigned cp, std::string& out) {
@@ -251,10 +292,21 @@ class Parser {
           case 'f': out += '\f'; break;
           case 'u': {
             unsigned cp = hex4();
-            if (cp >= 0xD800 && cp < 0xDC00 && end_ - p_ >= 6 && p_[0] == '\\' && p_[1] == 'u') {
-              p_ += 2;
-              unsigned lo = hex4();
-              cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+            if (cp >= 0xD800 && cp < 0xDC00) {
+              // a high surrogate counts only with its low half; alone it becomes U+FFFD
+              unsigned lo = 0;
+              if (end_ - p_ >= 6 && p_[0] == '\\' && p_[1] == 'u') {
+                const char* save = p_;
+                p_ += 2;
+                lo = hex4();
+                if (lo < 0xDC00 || lo > 0xDFFF) {
+                  p_ = save;
+                  lo = 0;
+                }
+              }
+              cp = lo ? 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00) : 0xFFFD;
+            } else if (cp >= 0xDC00 && cp <= 0xDFFF) {
+              cp = 0xFFFD;
             }
             utf8(cp, out);
             break;
@@ -270,6 +322,8 @@ class Parser {
     return out;
   }
   Value array() {
+    Nest nest(depth_);
+    if (depth_ > kMaxDepth) fail("nested too deeply");
     ++p_;
     Value v = Value::array();
     ws();
@@ -284,6 +338,8 @@ class Parser {
     }
   }
   Value object() {
+    Nest nest(depth_);
+    if (depth_ > kMaxDepth) fail("nested too deeply");
     ++p_;
     Value v = Value::object();
     ws();

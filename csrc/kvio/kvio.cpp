@@ -23,6 +23,8 @@
 #include <mutex>
 #include <vector>
 
+#include "rangecoder.hpp"
+
 #define API extern "C" __attribute__((visibility("default")))
 
 namespace {
@@ -197,127 +199,15 @@ API int kvio_load_pages(void* h, void* dev_base, size_t page_bytes, const int64_
 }
 
 // ---------------------------------------------------------------- entropy coder (host)
-// Adaptive binary range coder (LZMA-style rc) over int8 symbols decomposed with a
-// per-context binary tree: 8 binary decisions per symbol, context = tree node.  Narrow
-// alphabets (late layers quantised to few levels) cost proportionally fewer bits.
-namespace {
-
-struct RcEnc {
-  uint64_t low = 0;
-  uint32_t range = 0xFFFFFFFFu;
-  uint8_t cache = 0;
-  uint64_t cache_size = 1;
-  uint8_t* out;
-  size_t cap, pos = 0;
-  bool overflow = false;
-  void put(uint8_t b) {
-    if (pos < cap)
-      out[pos++] = b;
-    else
-      overflow = true;
-  }
-  void shift_low() {
-    if ((uint32_t)low < 0xFF000000u || (int)(low >> 32) != 0) {
-      uint8_t temp = cache;
-      do {
-        put((uint8_t)(temp + (uint8_t)(low >> 32)));
-        temp = 0xFF;
-      } while (--cache_size != 0);
-      cache = (uint8_t)((uint32_t)low >> 24);
-    }
-    cache_size++;
-    low = (uint32_t)low << 8;
-  }
-  void encode(uint16_t* prob, int bit) {
-    uint32_t bound = (range >> 11) * *prob;
-    if (!bit) {
-      range = bound;
-      *prob += (2048 - *prob) >> 5;
-    } else {
-      low += bound;
-      range -= bound;
-      *prob -= *prob >> 5;
-    }
-    while (range < (1u << 24)) {
-      range <<= 8;
-      shift_low();
-    }
-  }
-  void flush() {
-    for (int i = 0; i < 5; ++i) shift_low();
-  }
-};
-
-struct RcDec {
-  uint32_t range = 0xFFFFFFFFu, code = 0;
-  const uint8_t* in;
-  size_t len, pos = 0;
-  uint8_t get() { return pos < len ? in[pos++] : 0; }
-  void init() {
-    get();
-    for (int i = 0; i < 4; ++i) code = (code << 8) | get();
-  }
-  int decode(uint16_t* prob) {
-    uint32_t bound = (range >> 11) * *prob;
-    int bit;
-    if (code < bound) {
-      range = bound;
-      *prob += (2048 - *prob) >> 5;
-      bit = 0;
-    } else {
-      code -= bound;
-      range -= bound;
-      *prob -= *prob >> 5;
-      bit = 1;
-    }
-    while (range < (1u << 24)) {
-      range <<= 8;
-      code = (code << 8) | get();
-    }
-    return bit;
-  }
-};
-
-}  // namespace
-
-// Returns bytes written, or -1 when `cap` is too small.  n_ctx independent model sets are
-// cycled every `ctx_period` symbols (e.g. one per layer) so each layer adapts separately.
+// The coder itself is host-only code in rangecoder.hpp (built and fuzzed under sanitizers by the
+// CPU test suite); these are its C entry points.
 API int64_t kvio_rc_encode(const int8_t* sym, size_t n, uint8_t* out, size_t cap, size_t ctx_period,
                            int n_ctx) {
-  if (n_ctx < 1) n_ctx = 1;
-  if (ctx_period == 0) ctx_period = n ? n : 1;
-  std::vector<uint16_t> probs((size_t)n_ctx * 256, 1024);
-  RcEnc e;
-  e.out = out;
-  e.cap = cap;
-  for (size_t i = 0; i < n; ++i) {
-    uint16_t* pr = probs.data() + ((i / ctx_period) % n_ctx) * 256;
-    unsigned v = (uint8_t)sym[i] ^ 0x80u;  // order symbols by value: -128..127 -> 0..255
-    unsigned node = 1;
-    for (int b = 7; b >= 0; --b) {
-      int bit = (v >> b) & 1;
-      e.encode(pr + node, bit);
-      node = (node << 1) | bit;
-    }
-  }
-  e.flush();
-  return e.overflow ? -1 : (int64_t)e.pos;
+  return vrc::encode(sym, n, out, cap, ctx_period, n_ctx);
 }
 
+// 0 = ok, -1 = the stream ended before `n` symbols were decoded (truncated or not a stream)
 API int kvio_rc_decode(const uint8_t* in, size_t len, int8_t* sym, size_t n, size_t ctx_period,
                        int n_ctx) {
-  if (n_ctx < 1) n_ctx = 1;
-  if (ctx_period == 0) ctx_period = n ? n : 1;
-  std::vector<uint16_t> probs((size_t)n_ctx * 256, 1024);
-  RcDec d;
-  d.in = in;
-  d.len = len;
-  d.init();
-  for (size_t i = 0; i < n; ++i) {
-    uint16_t* pr = probs.data() + ((i / ctx_period) % n_ctx) * 256;
-    unsigned node = 1;
-    for (int b = 0; b < 8; ++b) node = (node << 1) | (unsigned)d.decode(pr + node);
-    sym[i] = (int8_t)((node & 0xFF) ^ 0x80u);
-  }
-  return 0;
+  return vrc::decode(in, len, sym, n, ctx_period, n_ctx);
 }

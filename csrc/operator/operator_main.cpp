@@ -5,19 +5,35 @@
 //       print the desired child objects as a JSON List (pipe into `kubectl apply -f -`)
 //   vpsa-operator plan-lora < {"cr": <LoraAdapter>, "pods": [{name, ip, ready, adapters[]}], "deleting": bool}
 //       print the load / unload actions the reconciler would take
-//   vpsa-operator run --api http://127.0.0.1:8001 [--namespace ns] [--interval 5] [--gpu-resource amd.com/gpu]
-//       level-triggered control loop against the API server (reached through `kubectl proxy`
-//       or any plain-HTTP endpoint): ensure child objects, update drifted fields, write CR
-//       status, load/unload LoRA adapters on engine pods, honour finalizers.
+//   vpsa-operator run --api http://127.0.0.1:8001 [--namespace ns] [--interval 30] [--gpu-resource amd.com/gpu]
+//                     [--leader-elect --leader-elect-namespace ns --leader-id id] [--health-port 8081]
+//       control loop against the API server (reached through `kubectl proxy` or any plain-HTTP
+//       endpoint): ensure child objects, update drifted fields, write CR status, load/unload
+//       LoRA adapters on engine pods, honour finalizers.
+//       Event-driven: one watch stream per custom resource kind plus one on the engine pods
+//       (?watch=true&resourceVersion=...) wakes the reconciler as soon as something changes; the
+//       interval is only the resync period.  With --leader-elect only the holder of the Lease
+//       `4549d26f.vllm.ai` (coordination.k8s.io/v1) reconciles; the others stand by and take
+//       over when the lease is not renewed.  The health port serves /healthz, /readyz and
+//       Prometheus text on /metrics.
 //
-// Reference (Go): /root/reference/operator/cmd/main.go:205-259 wires four reconcilers with
-// leader election and health probes; the reconcile semantics are cited in reconcile.hpp.
+// Reference (Go): /root/reference/operator/cmd/main.go:107-259 (manager with metrics server,
+// leader election id :187, health and ready probes :252-259, four reconcilers :205-233) and the
+// pod-ready watch predicate of /root/reference/operator/internal/controller/loraadapter_controller.go:234-275;
+// the reconcile semantics are cited in reconcile.hpp.
 #include <unistd.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <csignal>
 #include <cstdio>
+#include <ctime>
 #include <iostream>
 #include <iterator>
+#include <mutex>
 #include <set>
+#include <thread>
 
 #include "../common/http.hpp"
 #include "../common/json.hpp"
@@ -28,6 +44,39 @@ using vjson::Value;
 static const char* GROUP = "production-stack.vllm.ai";
 static const char* VERSION = "v1alpha1";
 static const char* FINALIZER = "production-stack.vllm.ai/lora-finalizer";
+static const char* LEASE_NAME = "4549d26f.vllm.ai";  // the reference manager's election id
+static int g_sidecar_port = 30090;
+
+// ------------------------------------------------------------------ metrics (Prometheus text)
+struct Metrics {
+  std::mutex mu;
+  std::map<std::string, double> values;  // full series name incl. labels -> value
+  void add(const std::string& series, double d = 1) {
+    std::lock_guard<std::mutex> lk(mu);
+    values[series] += d;
+  }
+  void set(const std::string& series, double v) {
+    std::lock_guard<std::mutex> lk(mu);
+    values[series] = v;
+  }
+  std::string render() {
+    std::lock_guard<std::mutex> lk(mu);
+    std::string out, last;
+    for (auto& kv : values) {
+      std::string base = kv.first.substr(0, kv.first.find('{'));
+      if (base != last) {
+        bool counter = base.size() > 6 && base.compare(base.size() - 6, 6, "_total") == 0;
+        out += "# TYPE " + base + (counter ? " counter\n" : " gauge\n");
+        last = base;
+      }
+      char num[64];
+      snprintf(num, sizeof num, "%.17g", kv.second);
+      out += kv.first + " " + num + "\n";
+    }
+    return out;
+  }
+};
+static Metrics g_metrics;
 
 struct Api {
   std::string base, token;
@@ -126,6 +175,7 @@ static void reconcile_simple(const Api& api, const Value& cr, const std::string&
     if (r != "unchanged") fprintf(stderr, "[%s/%s] %s %s: %s\n", plural_name.c_str(), cr.s("metadata.name").c_str(),
                                   obj.s("kind").c_str(), obj.s("metadata.name").c_str(), r.c_str());
     if (r.find("failed") != std::string::npos) ok = false;
+    if (r != "unchanged") g_metrics.add("vpsa_operator_child_objects_total{kind=\"" + obj.s("kind") + "\",result=\"" + r.substr(0, r.find('(')) + "\"}");
   }
   Value st = Value::object();
   st.set("status", ok ? deployment_phase(api, cr.s("metadata.namespace", "default"), cr.s("metadata.name")) : "NotReady");
@@ -182,10 +232,25 @@ static void reconcile_lora(const Api& api, const Value& cr) {
     patch.set("metadata", m);
     api.send("PATCH", path, patch, "application/merge-patch+json");
   }
-  int port = (int)cr.n("spec.vllmPort", 8000);
+  int port = (int)cr.i("spec.vllmPort", 8000, 1, 65535);
   // huggingface source: ask the download sidecar (port 30090) of each target pod first
   auto pods = observe_pods(api, ns, cr.s("spec.baseModel"), port);
   auto acts = vop::plan_lora(cr, pods, deleting);
+  if (deleting) {
+    // unload everywhere the adapter is known to be: what the pods list AND what this CR's status
+    // recorded (an engine's model listing can lag behind its loaded adapters)
+    const Value& rec = cr.at("status.loadedAdapters");
+    if (rec.is_arr())
+      for (auto& e : *rec.arr) {
+        const std::string pod_name = e.s("podName");
+        bool planned = false;
+        for (auto& a : acts) planned = planned || a.pod == pod_name;
+        if (planned) continue;
+        for (auto& p : pods)
+          if (p.name == pod_name && !p.ip.empty())
+            acts.push_back({"unload", p.name, p.ip, cr.s("spec.adapterSource.adapterName"), ""});
+      }
+  }
   Value loaded = Value::array();
   std::string phase = "Ready", message;
   for (auto& a : acts) {
@@ -198,7 +263,7 @@ static void reconcile_lora(const Api& api, const Value& cr) {
         dl.set("model_id", cr.s("spec.adapterSource.repository"));
         dl.set("local_dir", a.adapter);
         std::string r;
-        int st = vhttp::request("POST", "http://" + a.ip + ":30090", "/model/download", vjson::dump(dl), &r);
+        int st = vhttp::request("POST", "http://" + a.ip + ":" + std::to_string(g_sidecar_port), "/model/download", vjson::dump(dl), &r);
         if (st == 200) {
           try {
             std::string p = vjson::parse(r).s("path");
@@ -220,10 +285,12 @@ static void reconcile_lora(const Api& api, const Value& cr) {
         phase = "Failed";
         message = "load failed on " + a.pod + " (" + std::to_string(st) + ")";
       }
+      g_metrics.add(std::string("vpsa_operator_lora_actions_total{op=\"load\",result=\"") + (st == 200 ? "ok" : already ? "already_loaded" : "failed") + "\"}");
     } else {
       Value req = Value::object();
       req.set("lora_name", a.adapter);
-      vhttp::request("POST", engine, "/v1/unload_lora_adapter", vjson::dump(req), &body, "application/json", bearer);
+      int st = vhttp::request("POST", engine, "/v1/unload_lora_adapter", vjson::dump(req), &body, "application/json", bearer);
+      g_metrics.add(std::string("vpsa_operator_lora_actions_total{op=\"unload\",result=\"") + (st == 200 ? "ok" : "failed") + "\"}");
     }
   }
   if (deleting) {
@@ -285,18 +352,137 @@ static void run_once(const Api& api, const std::string& ns, const std::string& g
           reconcile_simple(api, cr, k.plural, vop::desired_for_router(cr));
         } else if (kk == "CacheServer") reconcile_simple(api, cr, k.plural, vop::desired_for_cacheserver(cr));
         else reconcile_lora(api, cr);
+        g_metrics.add(std::string("vpsa_operator_reconcile_total{kind=\"") + k.kind + "\",result=\"ok\"}");
       } catch (const std::exception& e) {
         fprintf(stderr, "reconcile %s/%s failed: %s\n", k.plural, cr.s("metadata.name").c_str(), e.what());
+        g_metrics.add(std::string("vpsa_operator_reconcile_total{kind=\"") + k.kind + "\",result=\"error\"}");
       }
     }
   }
+}
+
+// ------------------------------------------------------------------ event-driven wake-up
+// Reconciliation stays level-triggered (every pass looks at the whole state); the watch streams
+// only decide WHEN a pass runs: at once after any change to a custom resource or to an engine
+// pod (a pod turning ready is what lets a pending LoRA adapter load: the reference's watch
+// predicate), otherwise at the resync interval.
+struct Wakeup {
+  std::mutex mu;
+  std::condition_variable cv;
+  bool dirty = true;  // first pass runs immediately
+  void notify() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      dirty = true;
+    }
+    cv.notify_all();
+  }
+  // true: woken by an event, false: the interval passed
+  bool wait(int seconds) {
+    std::unique_lock<std::mutex> lk(mu);
+    bool ev = cv.wait_for(lk, std::chrono::seconds(seconds), [&] { return dirty; });
+    dirty = false;
+    return ev;
+  }
+};
+static Wakeup g_wake;
+static std::atomic<bool> g_stop{false};
+
+static void watch_loop(Api api, std::string list_path, std::string label) {
+  const std::string sep = list_path.find('?') == std::string::npos ? "?" : "&";
+  while (!g_stop) {
+    Value list;
+    std::string rv;
+    if (api.get(list_path, &list) == 200) rv = list.s("metadata.resourceVersion");
+    std::string path = list_path + sep + "watch=true&allowWatchBookmarks=true&timeoutSeconds=300";
+    if (!rv.empty()) path += "&resourceVersion=" + rv;
+    int st = vhttp::stream_lines(api.base, path, api.token, [&](const std::string& line) {
+      if (g_stop) return false;
+      try {
+        Value ev = vjson::parse(line);
+        std::string type = ev.s("type");
+        if (type == "ERROR") return false;  // e.g. 410 Gone: list again for a fresh resourceVersion
+        if (type != "BOOKMARK") {
+          g_metrics.add("vpsa_operator_watch_events_total{resource=\"" + label + "\",type=\"" + type + "\"}");
+          g_wake.notify();
+        }
+      } catch (...) {
+        return false;  // not an event line: start over rather than guess
+      }
+      return true;
+    }, 330);
+    if (st != 200) g_metrics.add("vpsa_operator_watch_restarts_total{resource=\"" + label + "\"}");
+    // the stream ended (server timeout, error, 410): re-list and watch again, after a breath
+    for (int i = 0; i < 5 && !g_stop; ++i) usleep(100 * 1000);
+  }
+}
+
+// ------------------------------------------------------------------ leader election (Lease)
+static std::string rfc3339_now() {
+  timespec ts{};
+  clock_gettime(CLOCK_REALTIME, &ts);
+  tm t{};
+  gmtime_r(&ts.tv_sec, &t);
+  char buf[64];
+  snprintf(buf, sizeof buf, "%04d-%02d-%02dT%02d:%02d:%02d.%06ldZ", t.tm_year + 1900, t.tm_mon + 1, t.tm_mday,
+           t.tm_hour, t.tm_min, t.tm_sec, ts.tv_nsec / 1000);
+  return buf;
+}
+
+static double parse_rfc3339(const std::string& s) {
+  tm t{};
+  if (s.size() < 19 || !strptime(s.substr(0, 19).c_str(), "%Y-%m-%dT%H:%M:%S", &t)) return 0;
+  double frac = 0;
+  if (s.size() > 20 && s[19] == '.') frac = atof(("0" + s.substr(19, s.find_first_not_of("0123456789", 20) - 19)).c_str());
+  return (double)timegm(&t) + frac;
+}
+
+// One round of the election: create the Lease, renew our own, or take over an expired one.
+// Returns true while this process holds it.  Optimistic concurrency: every write carries the
+// resourceVersion it read, a 409 means somebody else wrote first and we are not the leader.
+static bool elect_once(const Api& api, const std::string& ns, const std::string& id, int duration_s) {
+  const std::string coll = "/apis/coordination.k8s.io/v1/namespaces/" + ns + "/leases";
+  Value lease;
+  int st = api.get(coll + "/" + LEASE_NAME, &lease);
+  const std::string now = rfc3339_now();
+  auto spec = [&](double transitions, const std::string& acquired) {
+    Value sp = Value::object();
+    sp.set("holderIdentity", id);
+    sp.set("leaseDurationSeconds", (double)duration_s);
+    sp.set("acquireTime", acquired);
+    sp.set("renewTime", now);
+    sp.set("leaseTransitions", transitions);
+    return sp;
+  };
+  if (st == 404) {
+    Value obj = Value::object(), meta = Value::object();
+    obj.set("apiVersion", "coordination.k8s.io/v1");
+    obj.set("kind", "Lease");
+    meta.set("name", LEASE_NAME);
+    meta.set("namespace", ns);
+    obj.set("metadata", meta);
+    obj.set("spec", spec(0, now));
+    int c = api.send("POST", coll, obj);
+    return c >= 200 && c < 300;
+  }
+  if (st != 200) return false;
+  const std::string holder = lease.s("spec.holderIdentity");
+  const double renewed = parse_rfc3339(lease.s("spec.renewTime"));
+  const double dur = lease.n("spec.leaseDurationSeconds", duration_s);
+  const bool mine = holder == id;
+  const bool expired = holder.empty() || parse_rfc3339(now) > renewed + dur;
+  if (!mine && !expired) return false;
+  Value upd = lease;
+  upd.set("spec", spec(lease.n("spec.leaseTransitions") + (mine ? 0 : 1), mine ? lease.s("spec.acquireTime", now) : now));
+  int c = api.send("PUT", coll + "/" + LEASE_NAME, upd);
+  return c >= 200 && c < 300;
 }
 
 static std::string slurp_stdin() { return std::string(std::istreambuf_iterator<char>(std::cin), std::istreambuf_iterator<char>()); }
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    fprintf(stderr, "usage: vpsa-operator render <Kind> | plan-lora | run --api URL [--namespace ns] [--interval s]\n");
+    fprintf(stderr, "usage: vpsa-operator render <Kind> | plan-lora | run --api URL [--namespace ns] [--interval s] [--leader-elect] [--health-port p]\n");
     return 2;
   }
   std::string mode = argv[1];
@@ -345,9 +531,9 @@ int main(int argc, char** argv) {
     }
     if (mode == "run") {
       Api api;
-      std::string ns, gpu = "amd.com/gpu";
-      int interval = 5, health_port = 8081;
-      bool once = false;
+      std::string ns, gpu = "amd.com/gpu", lease_ns, leader_id;
+      int interval = 30, health_port = 8081, lease_s = 15;
+      bool once = false, leader_elect = false, watch = true;
       for (int i = 2; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> std::string { return i + 1 < argc ? argv[++i] : ""; };
@@ -357,25 +543,96 @@ int main(int argc, char** argv) {
         else if (a == "--interval") interval = atoi(next().c_str());
         else if (a == "--gpu-resource") gpu = next();
         else if (a == "--health-port") health_port = atoi(next().c_str());
+        else if (a == "--sidecar-port") g_sidecar_port = atoi(next().c_str());
+        else if (a == "--leader-elect") leader_elect = true;
+        else if (a == "--leader-elect-namespace") lease_ns = next();
+        else if (a == "--leader-id") leader_id = next();
+        else if (a == "--lease-duration") lease_s = atoi(next().c_str());
+        else if (a == "--no-watch") watch = false;
         else if (a == "--once") once = true;
       }
       if (api.base.empty()) {
         fprintf(stderr, "--api is required (e.g. http://127.0.0.1:8001 from `kubectl proxy`)\n");
         return 2;
       }
+      if (once) {
+        run_once(api, ns, gpu);
+        return 0;
+      }
+      if (interval < 1) interval = 1;
+      if (lease_s < 2) lease_s = 2;
+      if (lease_ns.empty()) lease_ns = ns.empty() ? "default" : ns;
+      if (leader_id.empty()) {
+        char host[256] = "operator";
+        gethostname(host, sizeof host - 1);
+        leader_id = std::string(host) + "_" + std::to_string((long)getpid());
+      }
+      signal(SIGTERM, [](int) { g_stop = true; g_wake.notify(); });
+      signal(SIGINT, [](int) { g_stop = true; g_wake.notify(); });
+      std::atomic<bool> leader{!leader_elect};
+      std::atomic<bool> election_alive{!leader_elect};
+      g_metrics.set("vpsa_operator_leader", leader ? 1 : 0);
       vhttp::Server health;
-      if (!once && health_port > 0)
-        health.start("0.0.0.0", health_port, [](const vhttp::Request& r) {
+      if (health_port > 0) {
+        int bound = health.start("0.0.0.0", health_port, [&](const vhttp::Request& r) {
           vhttp::Response resp;
-          resp.body = (r.path == "/healthz" || r.path == "/readyz") ? "ok" : "not found";
-          resp.status = (r.path == "/healthz" || r.path == "/readyz") ? 200 : 404;
           resp.content_type = "text/plain";
+          if (r.path == "/healthz") resp.body = "ok";
+          else if (r.path == "/readyz") {
+            // ready = taking part in the election (leader or standby); both may be sent traffic-free probes
+            resp.status = election_alive ? 200 : 503;
+            resp.body = election_alive ? "ok" : "election loop not running";
+          } else if (r.path == "/metrics") {
+            resp.content_type = "text/plain; version=0.0.4";
+            resp.body = g_metrics.render();
+          } else {
+            resp.status = 404;
+            resp.body = "not found";
+          }
           return resp;
         });
-      do {
+        if (!bound) fprintf(stderr, "could not bind health port %d\n", health_port);
+      }
+      std::vector<std::thread> threads;
+      if (leader_elect)
+        threads.emplace_back([&] {
+          // renew at a third of the lease duration: two missed rounds still leave a margin
+          while (!g_stop) {
+            bool now_leader = false;
+            try {
+              now_leader = elect_once(api, lease_ns, leader_id, lease_s);
+            } catch (...) {
+            }
+            election_alive = true;
+            if (now_leader != leader) {
+              fprintf(stderr, "[leader-election] %s %s\n", leader_id.c_str(), now_leader ? "became leader" : "lost the lease");
+              g_metrics.add("vpsa_operator_leader_transitions_total");
+              leader = now_leader;
+              g_metrics.set("vpsa_operator_leader", now_leader ? 1 : 0);
+              if (now_leader) g_wake.notify();
+            }
+            for (int i = 0; i < lease_s * 10 / 3 && !g_stop; ++i) usleep(100 * 1000);
+          }
+        });
+      if (watch) {
+        const std::string crd_root = std::string("/apis/") + GROUP + "/" + VERSION + (ns.empty() ? "" : "/namespaces/" + ns) + "/";
+        for (const char* plural_name : {"vllmruntimes", "vllmrouters", "cacheservers", "loraadapters"})
+          threads.emplace_back(watch_loop, api, crd_root + plural_name, std::string(plural_name));
+        // engine pods carry the label `model` (the chart and the runtime controller stamp it)
+        threads.emplace_back(watch_loop, api, std::string("/api/v1") + (ns.empty() ? "" : "/namespaces/" + ns) + "/pods?labelSelector=model",
+                             std::string("pods"));
+      }
+      while (!g_stop) {
+        bool by_event = g_wake.wait(interval);
+        if (g_stop) break;
+        if (!leader) continue;
+        g_metrics.add(std::string("vpsa_operator_passes_total{trigger=\"") + (by_event ? "event" : "resync") + "\"}");
         run_once(api, ns, gpu);
-        if (!once) sleep((unsigned)interval);
-      } while (!once);
+        g_metrics.set("vpsa_operator_last_pass_timestamp_seconds", (double)time(nullptr));
+        if (by_event) usleep(200 * 1000);  // a burst of events becomes one pass, not one pass each
+      }
+      health.stop();
+      for (auto& t : threads) t.detach();  // blocked in reads with a timeout; the process is exiting
       return 0;
     }
   } catch (const std::exception& e) {

@@ -88,7 +88,7 @@ inline Value service(const std::string& name, const std::string& ns, const Value
 // ------------------------------------------------------------------ VLLMRuntime
 inline std::vector<std::string> runtime_args(const Value& cr) {
   const Value& sp = cr.at("spec");
-  int port = (int)sp.n("vllmConfig.port", 8000);
+  int port = (int)sp.i("vllmConfig.port", 8000, 1, 65535);
   std::vector<std::string> a = {sp.s("model.modelURL"), "--host", "0.0.0.0", "--port", num(port)};
   if (sp.flag("model.enableLoRA")) a.push_back("--enable-lora");
   if (sp.flag("model.enableTool")) a.push_back("--enable-auto-tool-choice");
@@ -207,7 +207,7 @@ inline Value probe(const std::string& path, int port, int initial, int period, i
 inline std::vector<Value> desired_for_runtime(const Value& cr, const std::string& gpu_resource = "amd.com/gpu") {
   const Value& sp = cr.at("spec");
   const std::string name = cr.s("metadata.name"), ns = cr.s("metadata.namespace", "default");
-  int port = (int)sp.n("vllmConfig.port", 8000);
+  int port = (int)sp.i("vllmConfig.port", 8000, 1, 65535);
   std::vector<Value> out;
   out.push_back(service(name, ns, cr, name, 80, port));
   const Value& st = sp.at("storageConfig");
@@ -308,7 +308,7 @@ inline std::vector<Value> desired_for_runtime(const Value& cr, const std::string
   tmpl.set("metadata", tmeta);
   tmpl.set("spec", podspec);
   Value dsp = Value::object();
-  dsp.set("replicas", (int)sp.n("deploymentConfig.replicas", 1));
+  dsp.set("replicas", (int)sp.i("deploymentConfig.replicas", 1, 0, 100000));
   Value sel = Value::object();
   Value ml = Value::object();
   ml.set("app", name);
@@ -377,7 +377,7 @@ inline std::vector<Value> desired_for_router(const Value& cr) {
   const Value& sp = cr.at("spec");
   const std::string name = cr.s("metadata.name"), ns = cr.s("metadata.namespace", "default");
   const std::string sa = sp.s("serviceAccountName", name + "-sa");
-  int port = (int)sp.n("port", 80);
+  int port = (int)sp.i("port", 80, 1, 65535);
   std::vector<Value> out;
   Value acct = Value::object();
   acct.set("apiVersion", "v1");
@@ -463,7 +463,7 @@ inline std::vector<Value> desired_for_router(const Value& cr) {
   tmpl.set("metadata", tmeta);
   tmpl.set("spec", podspec);
   Value dsp = Value::object();
-  dsp.set("replicas", (int)sp.n("replicas", 1));
+  dsp.set("replicas", (int)sp.i("replicas", 1, 0, 100000));
   Value ml = Value::object();
   ml.set("app", name);
   Value sel = Value::object();
@@ -483,7 +483,7 @@ inline std::vector<Value> desired_for_router(const Value& cr) {
 inline std::vector<Value> desired_for_cacheserver(const Value& cr) {
   const Value& sp = cr.at("spec");
   const std::string name = cr.s("metadata.name"), ns = cr.s("metadata.namespace", "default");
-  int port = (int)sp.n("port", 8000);
+  int port = (int)sp.i("port", 8000, 1, 65535);
   std::vector<Value> out;
   out.push_back(service(name, ns, cr, name, 80, port));
   Value c = Value::object();
@@ -510,7 +510,7 @@ inline std::vector<Value> desired_for_cacheserver(const Value& cr) {
   tmpl.set("metadata", tmeta);
   tmpl.set("spec", podspec);
   Value dsp = Value::object();
-  dsp.set("replicas", (int)sp.n("replicas", 1));
+  dsp.set("replicas", (int)sp.i("replicas", 1, 0, 100000));
   Value ml = Value::object();
   ml.set("app", name);
   Value sel = Value::object();
@@ -544,7 +544,7 @@ struct LoraAction {
 // adapters first (spreads adapters over the fleet).  replicas <= 0 means every ready pod.
 inline std::vector<std::string> place_adapter(const Value& cr, std::vector<PodState> pods) {
   const std::string algo = cr.s("spec.loraAdapterDeploymentConfig.algorithm", "default");
-  int replicas = (int)cr.n("spec.loraAdapterDeploymentConfig.replicas", 0);
+  int replicas = (int)cr.i("spec.loraAdapterDeploymentConfig.replicas", 0, 0, 100000);
   const std::string adapter = cr.s("spec.adapterSource.adapterName");
   std::vector<PodState> ready;
   for (auto& p : pods)

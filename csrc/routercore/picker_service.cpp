@@ -116,7 +116,7 @@ struct Picker {
         try {
           Value r = vjson::parse(resp);
           std::string target = r.s("instance_id");
-          matched = (long)r.n("tokens");
+          matched = (long)r.i("tokens", 0, 0);
           long need = std::max(fields(prompt) - threshold, 0L);
           if (!target.empty() && matched >= need) {
             for (auto& p : pods) {

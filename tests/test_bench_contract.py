@@ -11,7 +11,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--device", "cpu", "--model", "tiny-llama", "--users-per-gpu", "3", "--warmup-users-per-gpu", "1",
          "--sys-len", "40", "--history-len", "200", "--answer-len", "8", "--max-model-len", "2048",
-         "--max-num-batched-tokens", "512"]
+         "--max-num-batched-tokens", "512", "--reference-users-per-gpu", "2",
+         "--reference-rounds", "2", "--reference-offload-gb", "0.05"]
 FIELDS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
           "vs_baseline", "dtype", "data", "config")
 
@@ -39,6 +40,13 @@ def test_two_ranks_under_torchrun():
     assert res["config"]["global_batch"] == 6 and res["requests"] == 12 and res["failed_requests"] == 0
     assert res["value"] > 0 and abs(res["ms_per_step"] - res["elapsed_s"] / 2 * 1e3) < 1.0
     assert len(res["per_replica"]) == 2 and all(r["rows"] > 0 for r in res["per_replica"])
+    # the second phase (the reference's own configuration) rides along and used the host tier
+    ref = res["reference_config"]
+    assert "error" not in ref, ref
+    assert ref["failed_requests"] == 0 and ref["requests"] == 2 * 2 * 2 and ref["output_tok_per_s"] > 0
+    assert ref["kv_tiers"]["host_stores_pages"] > 0
+    assert sum(r.get("host_loads_pages", 0) for r in ref["per_replica"]) > 0
+    assert "Failed to scrape" not in p.stderr  # engines outlive the router at teardown
 
 
 def test_single_process_defaults_to_one_gpu():

@@ -56,6 +56,32 @@ def test_page_serde_naive_and_cachegen():
     assert (x - back).abs().mean() / x.abs().mean() < 0.15
 
 
+def test_damaged_page_blobs_are_refused_not_decoded():
+    """Blobs come back from disk and from other hosts: a cut, padded or corrupted one has to be
+    a ValueError (the tier code turns that into a cache miss), never a page of wrong values."""
+    import pytest
+
+    n_layers, n_kv, hd = 3, 1, 128
+    page = torch.randn(n_layers * 2 * n_kv * 64 * hd).to(torch.bfloat16)
+    with pytest.raises(ValueError):
+        rc_decode(rc_encode(np.zeros(50000, np.int8) + 3, 0, 1)[:10], 50000, 0, 1)
+    with pytest.raises(ValueError):
+        rc_decode(b"", 100, 0, 1)
+    for kind in ("naive", "cachegen"):
+        sd = PageSerde(n_layers, n_kv, hd, torch.bfloat16, kind, levels=[127, 31, 15])
+        blob = sd.encode(page)
+        sd.decode(blob, torch.device("cpu"))
+        for bad in (b"", blob[:7], blob[:len(blob) // 2], blob[:-1], blob + b"x", b"\x00" * len(blob),
+                    blob[:4] + b"\xff" * 8 + blob[12:]):
+            with pytest.raises(ValueError):
+                sd.decode(bad, torch.device("cpu"))
+            with pytest.raises(ValueError):
+                sd.unpack(bad)
+    other = PageSerde(n_layers + 1, n_kv, hd, torch.bfloat16, "naive")
+    with pytest.raises(ValueError):
+        other.decode(blob, torch.device("cpu"))
+
+
 def test_rans_reference_roundtrip_and_gain():
     """NumPy definition of the GPU entropy stage: exact round trip on Gaussian, constant and
     uniform contexts, output close to the zeroth-order entropy."""
@@ -331,3 +357,24 @@ def test_controller_reporting_and_pd_push(api_key):
     finally:
         asyncio.run_coroutine_threadsafe(runner.cleanup(), loop).result(10)
         loop.call_soon_threadsafe(loop.stop)
+
+
+def test_prefix_caching_off_with_host_tier_serves_every_turn_from_host():
+    """``--no-enable-prefix-caching`` + CPU offload (the reference's benchmark configuration): HBM
+    keeps nothing between requests, a repeated prompt is loaded from the host tier."""
+    cfg = EngineConfig(model="tiny-llama", device="cpu", dtype="float32", max_model_len=1024,
+                       max_num_seqs=8, max_num_batched_tokens=256, num_gpu_blocks_override=24,
+                       enable_prefix_caching=False,
+                       kv_offload=KVOffloadConfig(local_cpu=True, max_local_cpu_gb=0.05), port=0)
+    eng = LLMEngine(cfg)
+    (a,) = prompts(1, 330, seed=21)
+    first = eng.generate([a], copy.deepcopy(SP))[0]
+    assert eng.bm.num_free() == 24 and not eng.bm.cached  # nothing stays in HBM
+    for _ in range(2):
+        r = eng.add_request(a, copy.deepcopy(SP))
+        while eng.has_work():
+            eng.step()
+        assert r.output_ids == first
+        assert r.num_cached_tokens == 0 and r.num_external_tokens == 320
+    assert eng.connector.host.loads >= 10
+    eng.shutdown()

@@ -47,9 +47,16 @@ def chain_hashes(token_ids: list[int], salt: bytes = b"", prev: int = 0, start_p
 
 class BlockManager:
     def __init__(self, num_pages: int, enable_prefix_caching: bool = True,
-                 on_evict: Callable[[int, int], None] | None = None):
+                 on_evict: Callable[[int, int], None] | None = None, reuse_in_hbm: bool = True):
+        """``enable_prefix_caching``: full pages are identified by their chain hash (needed by
+        the offload tiers and by transfers even when the engine's own prefix cache is off).
+        ``reuse_in_hbm`` False is ``--no-enable-prefix-caching`` with a KV connector configured
+        (the reference's benchmark setup, /root/reference/tutorials/07-benchmark-multi-round-qa-single-gpu.md:31-67):
+        pages are hashed and offloaded, but a finished request's pages go straight back to the
+        free list and a new request never finds its prefix in HBM - it comes from the tiers."""
         self.num_pages = num_pages
         self.enable_prefix_caching = enable_prefix_caching
+        self.reuse_in_hbm = reuse_in_hbm
         self.on_evict = on_evict
         self.ref = [0] * num_pages
         self.page_hash: list[int | None] = [None] * num_pages
@@ -74,7 +81,7 @@ class BlockManager:
         """Longest cached run from the start of ``hashes``; takes a reference on each page."""
         pages: list[int] = []
         hashes = list(hashes)
-        if self.enable_prefix_caching:
+        if self.enable_prefix_caching and self.reuse_in_hbm:
             for h in hashes:
                 p = self.cached.get(h)
                 if p is None:
@@ -89,6 +96,8 @@ class BlockManager:
 
     def peek_prefix(self, hashes: Iterable[int]) -> int:
         n = 0
+        if not self.reuse_in_hbm:
+            return 0
         for h in hashes:
             if h not in self.cached:
                 break
@@ -141,9 +150,15 @@ class BlockManager:
             self.ref[p] -= 1
             assert self.ref[p] >= 0
             if self.ref[p] == 0:
-                if self.page_hash[p] is not None:
+                h = self.page_hash[p]
+                if h is not None and self.reuse_in_hbm:
                     self.evictable[p] = None
                 else:
+                    if h is not None:  # hashed for the tiers only: nothing stays cached in HBM
+                        if self.on_evict is not None:
+                            self.on_evict(h, p)
+                        del self.cached[h]
+                        self.page_hash[p] = None
                     self.free_ids.append(p)
 
     def reset_prefix_cache(self) -> int:

@@ -37,7 +37,9 @@ class LLMEngine:
         self.max_model_len = self.runner.max_model_len
         self.tokenizer = load_tokenizer(self.ckpt_dir, self.model_cfg.vocab_size, cfg.chat_template)
         self.connector = None
-        self.bm = BlockManager(self.runner.num_pages, cfg.enable_prefix_caching or cfg.kv_offload.enabled)
+        # transfers publish pages through the prefix cache, so a P/D replica always reuses in HBM
+        self.bm = BlockManager(self.runner.num_pages, cfg.enable_prefix_caching or cfg.kv_offload.enabled,
+                               reuse_in_hbm=cfg.enable_prefix_caching or cfg.kv_transfer is not None)
         self.scheduler = Scheduler(self.bm, cfg.max_num_seqs, cfg.max_num_batched_tokens,
                                    self.max_model_len, cfg.enable_chunked_prefill)
         if self.device.type == "cuda" and cfg.prefill_step_ms > 0:
@@ -229,7 +231,13 @@ class LLMEngine:
     def is_sleeping(self) -> bool:
         return self.runner.sleeping
 
-    def shutdown(self) -> None:
+    def shutdown(self, release_memory: bool = True) -> None:
+        """Stop the side threads and (by default) free the device memory: weights, KV pool,
+        captured graphs, host-tier slab."""
         if self.connector is not None:
             self.connector.close()
         self.runner.stop_workers()
+        if release_memory:
+            if self.connector is not None:
+                self.connector.pool = None
+            self.runner.release()

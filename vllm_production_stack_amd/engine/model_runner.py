@@ -283,6 +283,36 @@ class ModelRunner:
         if self.distributed and self.replica.is_driver:
             replica_broadcast(("stop",))
 
+    def release(self) -> None:
+        """Give the device memory back: graphs first (they pin their private pool and every
+        tensor they captured), then the KV pool, the weights and the sampler state.  The runner
+        is unusable afterwards.  Needed because a stopped engine can stay reachable for a long
+        time (aiohttp keeps the handlers of a finished application in a module-level cache), and
+        reachable must not mean resident."""
+        import gc
+
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self._graphs.clear()
+        self._graph_pool = None
+        self._sleep_stash = []
+        # shrink the storages themselves: the transfer receiver, the tier connector and the
+        # attention layers hold views of the pool, and a view must not keep 200 GiB resident
+        stores = [self.pool] if self.pool is not None else []
+        if self.model is not None and hasattr(self.model, "weight_tensors"):
+            stores += list(self.model.weight_tensors())
+        for t in stores:
+            try:
+                t.untyped_storage().resize_(0)
+            except Exception:  # storage that cannot be resized (shared with another process)
+                pass
+        self.pool = None
+        self.model = None
+        self.sampler = None
+        gc.collect()
+        if self.device.type == "cuda":
+            torch.cuda.empty_cache()
+
     # ------------------------------------------------------------------ HIP-graph decode
     def _bucket(self, n: int) -> int:
         for b in _GRAPH_BUCKETS:

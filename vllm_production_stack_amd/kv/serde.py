@@ -66,7 +66,8 @@ def rc_encode(symbols: np.ndarray, ctx_period: int, n_ctx: int) -> bytes:
 def rc_decode(data: bytes, n: int, ctx_period: int, n_ctx: int) -> np.ndarray:
     buf = np.frombuffer(data, dtype=np.uint8)
     out = np.empty(n, dtype=np.int8)
-    kvio().kvio_rc_decode(buf.ctypes.data, buf.size, out.ctypes.data, n, ctx_period, n_ctx)
+    if kvio().kvio_rc_decode(buf.ctypes.data, buf.size, out.ctypes.data, n, ctx_period, n_ctx) != 0:
+        raise ValueError("range-coded KV payload is truncated or corrupt")
     return out
 
 
@@ -143,13 +144,35 @@ class PageSerde:
                 and page.dtype == torch.bfloat16)
 
     # ------------------------------------------------------------------ decode
-    def decode(self, blob: bytes, device: torch.device) -> torch.Tensor:
+    def _open(self, blob: bytes):
+        """Header checks shared by every decoder: (kind, payload).  Anything that is not a whole
+        page blob of this model's geometry is a ``ValueError``: blobs come from disk and from
+        other hosts, and a damaged one must read as a cache miss, never as a wrong page."""
+        if len(blob) < _HDR.size:
+            raise ValueError("not a KV page blob")
         magic, ver, kind, nl, nkv, hd, pt, plen = _HDR.unpack_from(blob, 0)
         if magic != MAGIC or ver != 1:
             raise ValueError("not a KV page blob")
         if (nl, nkv, hd, pt) != (self.n_layers, self.n_kv, self.head_dim, ops.PAGE):
             raise ValueError("KV page geometry mismatch")
-        payload = memoryview(blob)[_HDR.size:_HDR.size + plen]
+        if plen != len(blob) - _HDR.size:
+            raise ValueError("truncated KV page blob")
+        payload = memoryview(blob)[_HDR.size:]
+        if kind == SERDE_NAIVE:
+            if plen != self.page_elems * torch.empty((), dtype=self.dtype).element_size():
+                raise ValueError("KV page blob of the wrong size")
+        elif kind == SERDE_CACHEGEN_RANS:
+            if plen < _RANS_HDR.size:
+                raise ValueError("damaged cachegen payload")
+        elif kind == SERDE_CACHEGEN:
+            if plen < 4 * (self.page_elems // 64) + 8:
+                raise ValueError("damaged cachegen payload")
+        else:
+            raise ValueError(f"unknown KV page encoding {kind}")
+        return kind, payload
+
+    def decode(self, blob: bytes, device: torch.device) -> torch.Tensor:
+        kind, payload = self._open(blob)
         if kind == SERDE_NAIVE:
             t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).view(self.dtype)
             return t.to(device)
@@ -187,18 +210,15 @@ class PageSerde:
         n_groups = self.page_elems // 64
         scales = np.frombuffer(payload[: 4 * n_groups], dtype=np.float32).copy()
         (clen,) = struct.unpack_from("<Q", payload, 4 * n_groups)
-        coded = bytes(payload[4 * n_groups + 8: 4 * n_groups + 8 + clen])
+        if clen != len(payload) - 4 * n_groups - 8:
+            raise ValueError("damaged cachegen payload")
+        coded = bytes(payload[4 * n_groups + 8:])
         return rc_decode(coded, self.page_elems, 2 * self.unit_elems, self.n_layers), scales
 
     def unpack(self, blob: bytes):
         """Host half of decode for worker threads: ("raw", uint8 array) for a naive blob,
         ("codec", symbols, scales) for a cachegen one."""
-        magic, ver, kind, nl, nkv, hd, pt, plen = _HDR.unpack_from(blob, 0)
-        if magic != MAGIC or ver != 1:
-            raise ValueError("not a KV page blob")
-        if (nl, nkv, hd, pt) != (self.n_layers, self.n_kv, self.head_dim, ops.PAGE):
-            raise ValueError("KV page geometry mismatch")
-        payload = memoryview(blob)[_HDR.size:_HDR.size + plen]
+        kind, payload = self._open(blob)
         if kind == SERDE_NAIVE:
             return ("raw", np.frombuffer(payload, dtype=np.uint8).copy())
         if kind == SERDE_CACHEGEN_RANS:

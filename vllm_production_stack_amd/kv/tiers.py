@@ -91,6 +91,7 @@ class HostKVPool:
         if self.gpu and getattr(self, "h", None):
             self.lib.kvio_pool_destroy(self.h)
             self.h = None
+        self.host = None
 
     # ------------------------------------------------------------------ index
     def contains(self, h: int) -> bool:

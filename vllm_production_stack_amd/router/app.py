@@ -467,7 +467,10 @@ async def initialize_all(state: RouterState) -> None:
         state.batch_processor = initialize_batch_processor(
             args.batch_processor, args.file_storage_path, state.batch_storage,
             make_batch_dispatch(state))
-        await state.batch_processor.initialize()
+        from . import workers
+
+        # the queue is a SQLite file every worker can read and write; one of them executes it
+        await state.batch_processor.initialize(run_queue=workers.worker_index() == 0)
     path = args.dynamic_config_yaml or args.dynamic_config_json
     if path:
         state.tasks.append(asyncio.create_task(_dynamic_config_watcher(state, path)))
@@ -548,6 +551,12 @@ def main(argv: list[str] | None = None) -> None:
     set_level(args.log_level)
     set_ulimit()
     get_feature_gates()
+    from . import workers
+
+    n_workers = workers.effective_workers(args)
+    if n_workers > 1:
+        workers.run_workers(args, n_workers)
+        return
     app = create_app(args)
     web.run_app(app, host=args.host, port=args.port, access_log=None, backlog=8192,
                 print=lambda *a: logger.info("router listening on %s:%d", args.host, args.port))

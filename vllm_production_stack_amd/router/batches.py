@@ -99,9 +99,11 @@ class LocalBatchProcessor:
         return BatchInfo(**json.loads(row[0])) if row else None
 
     # -- lifecycle ---------------------------------------------------------------------
-    async def initialize(self) -> None:
+    async def initialize(self, run_queue: bool = True) -> None:
+        """``run_queue=False``: this process only serves the API (another router worker on the
+        same queue file executes the batches)."""
         self._conn()
-        if self._task is None:
+        if run_queue and self._task is None:
             self._task = asyncio.create_task(self._worker())
 
     async def close(self) -> None:

@@ -116,6 +116,9 @@ def build_parser() -> argparse.ArgumentParser:
     a("--prefix-trie-max-nodes", type=int, default=4_000_000,
       help="node budget of the prefix-aware trie (0 = unbounded)")
     a("--pii-analyzer", default="regex", choices=["regex", "presidio"])
+    a("--router-workers", type=int, default=1,
+      help="router processes sharing the listening port (SO_REUSEPORT); the prefix trie and the "
+           "round-robin position are shared between them")
     return p
 
 
@@ -142,6 +145,8 @@ def validate_args(args: argparse.Namespace) -> None:
         raise ValueError("K8s port must be provided when using K8s service discovery.")
     if args.routing_logic == "session" and args.session_key is None:
         raise ValueError("Session key must be provided when using session routing logic.")
+    if getattr(args, "router_workers", 1) < 1:
+        raise ValueError("--router-workers must be at least 1.")
     if args.log_stats and args.log_stats_interval <= 0:
         raise ValueError("Log stats interval must be greater than 0.")
     if args.engine_stats_interval <= 0:

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import abc
 import enum
+import asyncio
 import inspect
 import random
 
@@ -65,18 +66,26 @@ class RoutingInterface(abc.ABC):
 
 class RoundRobinRouter(RoutingInterface):
     def __init__(self):
+        from . import workers
+
         self.req_id = 0
         self._key = None
         self._sorted: list[str] = []
+        self._shared = workers.shared_rr_counter()  # one position for all router workers
 
     def route_request(self, endpoints, engine_stats, request_stats, request, request_json=None):
         key = tuple(e.url for e in endpoints)
         if key != self._key:
             self._sorted = sorted(key)
             self._key = key
-        chosen = self._sorted[self.req_id % len(self._sorted)]
-        self.req_id += 1
-        return chosen
+        if self._shared is not None:
+            with self._shared.get_lock():
+                n = self._shared.value
+                self._shared.value = n + 1
+        else:
+            n = self.req_id
+            self.req_id += 1
+        return self._sorted[n % len(self._sorted)]
 
 
 class SessionRouter(RoutingInterface):
@@ -123,7 +132,13 @@ class PrefixAwareRouter(RoutingInterface):
     the reference behaviour: any match wins, random choice among the matched endpoints."""
 
     def __init__(self, max_nodes: int = 4_000_000, min_match_ratio: float = 0.5):
-        self.hashtrie = HashTrie(chunk_size=128, max_nodes=max_nodes)
+        from . import workers
+
+        path = workers.shared_trie_path()
+        # with several router workers the trie lives in the supervisor process: every worker sees
+        # the prefixes any of them inserted
+        self.shared = workers.SharedTrieClient(path) if path else None
+        self.hashtrie = None if self.shared else HashTrie(chunk_size=128, max_nodes=max_nodes)
         self.min_match_ratio = min_match_ratio
 
     @staticmethod
@@ -135,18 +150,36 @@ class PrefixAwareRouter(RoutingInterface):
         best = min(load(u) for u in urls)
         return random.choice([u for u in urls if load(u) == best])
 
+    def _choose(self, prompt, available, matched_len, matched, request_stats) -> str:
+        strong = matched and matched_len >= self.min_match_ratio * len(prompt)
+        candidates = sorted(matched) if strong else sorted(available)
+        return self._least_loaded(candidates, request_stats)
+
     def route_request(self, endpoints, engine_stats, request_stats, request, request_json=None):
         prompt = extract_prompt_text(request_json or {})
         available = {e.url for e in endpoints}
+        if self.shared is not None:
+            return self._route_shared(prompt, available, request_stats)
         matched_len, matched = self.hashtrie.longest_prefix_match(prompt, available)
-        strong = matched and matched_len >= self.min_match_ratio * len(prompt)
-        candidates = sorted(matched) if strong else sorted(available)
-        selected = self._least_loaded(candidates, request_stats)
+        selected = self._choose(prompt, available, matched_len, matched, request_stats)
         self.hashtrie.insert(prompt, selected)
         return selected
 
+    async def _route_shared(self, prompt, available, request_stats) -> str:
+        matched_len, matched = await self.shared.longest_prefix_match(prompt, available)
+        selected = self._choose(prompt, available, matched_len, matched, request_stats)
+        await self.shared.insert(prompt, selected)
+        return selected
+
     def forget_endpoint(self, url: str) -> None:
-        self.hashtrie.remove_endpoint(url)
+        if self.shared is not None:
+            asyncio.ensure_future(self.shared.remove_endpoint(url))
+        else:
+            self.hashtrie.remove_endpoint(url)
+
+    async def close(self) -> None:
+        if self.shared is not None:
+            await self.shared.close()
 
 
 class KvawareRouter(RoutingInterface):
