@@ -162,6 +162,11 @@ class FakeKube:
         coll = request.path
         sel = request.query.get("labelSelector", "")
         q: asyncio.Queue = asyncio.Queue()
+        if request.query.get("resourceVersion", "") in ("", "0"):
+            # a watch that names no version starts with the current state, as ADDED events
+            for p, o in sorted(self.objects.items()):
+                if self.coll_of(p) == coll:
+                    q.put_nowait({"type": "ADDED", "object": copy.deepcopy(o)})
         self.watchers.setdefault(coll, []).append(q)
         resp = web.StreamResponse(headers={"Content-Type": "application/json"})
         resp.enable_chunked_encoding()
