@@ -7,6 +7,8 @@ same device in fp32; inputs are random (never zero-filled) and sized so that edg
 
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -587,6 +589,82 @@ def test_moe_grouped_mfma_experts(t, hidden, inter, skew):
         gu = xf[rows] @ w13[ex].float().t()
         a = torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:]
         exp.index_add_(0, rows, (a @ w2[ex].float().t()) * w[rows, slot].unsqueeze(1))
+    err = (out - exp).abs().max().item() / exp.abs().max().item()
+    assert err < 8e-3, err
+
+
+def _moe_fp32_definition(x, w13, w2, ids, w, inter):
+    t, hidden = x.shape
+    exp = torch.zeros((t, hidden), dtype=torch.float32, device=x.device)
+    xf = x.float()
+    for ex in range(w13.shape[0]):
+        rows, slot = (ids == ex).nonzero(as_tuple=True)
+        if rows.numel() == 0:
+            continue
+        gu = xf[rows] @ w13[ex].float().t()
+        a = torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:]
+        exp.index_add_(0, rows, (a @ w2[ex].float().t()) * w[rows, slot].unsqueeze(1))
+    return exp
+
+
+@pytest.mark.parametrize("m,n,k,groups", [
+    (256, 256, 64, [256]), (1000, 768, 512, [1000]), (4096, 1024, 4096, [4096]),
+    (3000, 512, 256, [0, 700, 1, 0, 1299, 255, 745, 0]), (777, 320, 192, [300, 477])])
+def test_grouped_gemm_against_fp32(m, n, k, groups):
+    """Grouped MFMA GEMM (device-side problem list): ragged group sizes including empty groups and
+    single rows, N and M that are not multiples of the tile, rows past the last group untouched."""
+    torch.manual_seed(31)
+    g = len(groups)
+    assert sum(groups) == m
+    a = (torch.rand(m + 50, k, device=DEV) * 2 - 1).to(BF)
+    w = ((torch.rand(g, n, k, device=DEV) * 2 - 1) * 0.1).to(BF)
+    off = torch.tensor([0] + list(np.cumsum(groups)), dtype=torch.int32, device=DEV)
+    out = torch.full((m + 50, n), 7.0, dtype=BF, device=DEV)
+    ops.grouped_gemm(a, w, off, rows=m + 50, out=out)
+    lo = 0
+    for i, cnt in enumerate(groups):
+        if cnt:
+            exp = a[lo:lo + cnt].float() @ w[i].float().t()
+            err = (out[lo:lo + cnt].float() - exp).abs().max().item() / exp.abs().max().item()
+            assert err < 6e-3, (i, err)
+        lo += cnt
+    assert (out[m:] == 7.0).all()  # rows that belong to no group are not written
+
+
+def test_grouped_gemm_gathered_rows_and_fused_swiglu():
+    torch.manual_seed(32)
+    t, k, inter, e = 600, 512, 384, 4
+    x = (torch.rand(t, k, device=DEV) * 2 - 1).to(BF)
+    w13 = ((torch.rand(e, 2 * inter, k, device=DEV) * 2 - 1) * 0.1).to(BF)
+    ids = torch.randint(0, e, (t, 2), device=DEV, dtype=torch.int32)
+    offsets, pos, sorted_tok = ops.moe_align(ids, e)
+    act = ops.grouped_gemm(x, w13, offsets, rows=2 * t, arow_idx=sorted_tok, silu_mul=True)
+    off = offsets.tolist()
+    for ex in range(e):
+        lo, hi = off[ex], off[ex + 1]
+        gu = x[sorted_tok[lo:hi].long()].float() @ w13[ex].float().t()
+        exp = torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:]
+        err = (act[lo:hi].float() - exp).abs().max().item() / exp.abs().max().item()
+        assert err < 8e-3, (ex, err)
+
+
+@pytest.mark.parametrize("t,hidden,inter,skew", [
+    (300, 512, 1024, False), (1024, 512, 1024, True), (4096, 4096, 14336, False)])
+def test_moe_prefill_grouped_gemm_experts(t, hidden, inter, skew):
+    """Prefill-sized expert MLP (grouped GEMMs over the device-sorted pairs, no host sync) against
+    the per-pair fp32 definition, up to a whole prefill chunk of Mixtral-8x7B shape."""
+    torch.manual_seed(23)
+    e, k = 8, 2
+    x = torch.randn(t, hidden, device=DEV).to(BF)
+    w13 = (torch.randn(e, 2 * inter, hidden, device=DEV) * 0.03).to(BF)
+    w2 = (torch.randn(e, hidden, inter, device=DEV) * 0.03).to(BF)
+    logits = torch.randn(t, e, device=DEV).to(BF)
+    if skew:
+        logits[:, 3] += 20.0
+        logits[:, 6] += 10.0
+    w, ids = ops.moe_topk_softmax(logits, k)
+    out = ops.moe_experts_prefill(x, w13, w2, ids, w).float()
+    exp = _moe_fp32_definition(x, w13, w2, ids, w, inter)
     err = (out - exp).abs().max().item() / exp.abs().max().item()
     assert err < 8e-3, err
 

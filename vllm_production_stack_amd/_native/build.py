@@ -29,7 +29,8 @@ TARGETS = {
     "vpsa_kernels": (
         "hip",
         ["kernels/elementwise.hip", "kernels/attention.hip", "kernels/kvcache.hip", "kernels/moe.hip",
-         "kernels/lora.hip", "kernels/gemm.hip", "kernels/rans.hip", "kernels/sampling.hip"],
+         "kernels/lora.hip", "kernels/gemm.hip", "kernels/rans.hip", "kernels/sampling.hip",
+         "kernels/grouped_gemm.hip"],
         [],
     ),
     "vpsa_kvio": ("hip", ["kvio/kvio.cpp"], []),

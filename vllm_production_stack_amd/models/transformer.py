@@ -199,6 +199,14 @@ class TransformerModel:
             act = ops.silu_and_mul(gu.view(e * t, -1)).view(e, t, -1)
             y = torch.matmul(act, lw.w2.transpose(1, 2))  # [E, T, H]
             return (y.float() * dense.t().unsqueeze(-1)).sum(0).to(x.dtype)
+        if (x.is_cuda and t <= ops.MOE_GROUPED_MAX_TOKENS
+                and ops.grouped_gemm_supported(2 * lw.w2.shape[2], x.shape[1], True)
+                and ops.grouped_gemm_supported(x.shape[1], lw.w2.shape[2])):
+            # Prefill chunks up to a few thousand tokens: two grouped matrix-core GEMMs over the
+            # device-sorted (token, expert) pairs.  The host never reads the per-expert counts, so
+            # it keeps launching ahead of the GPU.
+            return ops.moe_experts_prefill(x, lw.w13, lw.w2, ids, w)
+        # Whole 8k-token chunks: per-expert library GEMMs (row ranges needed on the host)
         offsets, pos, sorted_tok = ops.moe_align(ids, e)
         xs = ops.moe_permute(x, sorted_tok)
         off = offsets.tolist()
