@@ -50,26 +50,53 @@ def copy_engine(n_pages=384, batch=64):
     res["reload_gb_per_s"] = round(n_pages * page_bytes / dt / 1e9, 2)
     torch.cuda.synchronize()
     res["bit_exact"] = bool(torch.equal(pool, ref))
-    # overlap: reload while the compute stream runs GEMMs
+    # overlap: reload while the compute stream runs GEMMs.  Every timing is taken warm (the first
+    # pass of a loop also pays clock ramp-up and lazy initialisation) and repeated; the GEMM count
+    # is sized so that GEMMs alone take about as long as the reload alone.
     a = torch.randn(8192, 8192, device=DEV, dtype=torch.bfloat16)
-    for _ in range(3):
-        a @ a  # library warm-up (kernel selection, workspace)
+
+    def gemms(n):
+        for _ in range(n):
+            a @ a
+
+    def reload():
+        ev = None
+        for b in range(0, n_pages, batch):
+            ev = host.load([(1000 + p, p) for p in range(b, min(n_pages, b + batch))])
+        return ev
+
+    def wall(fn, reps=3):
+        best = float("inf")
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ev = fn()
+            torch.cuda.synchronize()
+            if ev is not None:
+                ev.wait()
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    gemms(20)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(40):
-        a @ a
-    torch.cuda.synchronize()
-    gemm_alone = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    for b in range(0, n_pages, batch):
-        ev = host.load([(1000 + p, p) for p in range(b, min(n_pages, b + batch))])
-    for _ in range(40):
-        a @ a
-    torch.cuda.synchronize()
-    ev.wait()
-    both = time.perf_counter() - t0
-    res["overlap"] = {"gemm_alone_s": round(gemm_alone, 4), "reload_alone_s": round(dt, 4),
-                      "both_concurrent_s": round(both, 4)}
+    one_gemm = wall(lambda: gemms(20)) / 20
+    reload_alone = wall(reload)
+    n_gemm = max(4, int(round(reload_alone / one_gemm)))
+    gemm_alone = wall(lambda: gemms(n_gemm))
+
+    def both():
+        ev = reload()
+        gemms(n_gemm)
+        return ev
+
+    concurrent = wall(both)
+    serial = gemm_alone + reload_alone
+    res["reload_under_compute"] = {
+        "gemms": n_gemm, "gemm_alone_s": round(gemm_alone, 4), "reload_alone_s": round(reload_alone, 4),
+        "serial_sum_s": round(serial, 4), "concurrent_wall_s": round(concurrent, 4),
+        # 1.0: the shorter of the two is hidden completely behind the longer; 0.0: they ran back to back
+        "hidden_fraction_of_the_shorter": round((serial - concurrent) / min(gemm_alone, reload_alone), 3),
+        "slowdown_vs_the_longer_alone_pct": round((concurrent / max(gemm_alone, reload_alone) - 1) * 100, 1)}
     host.close()
     return res
 

@@ -191,7 +191,9 @@ struct ArCtx {
   char* local;                 // ArShared + 2 * max_bytes
   char* peers[AR_MAX_RANKS];   // mapped peer buffers (own entry = local)
   uint32_t* epochs;            // [AR_BLOCKS] device counters
-  int* err;                    // device error word
+  int* err;                    // error word: pinned host memory mapped into the device
+  int* err_host;               // the host's view of it (readable without a device synchronisation)
+  int fine_grained;            // the published buffer is fine-grained device memory
 };
 
 struct ArArgs {
@@ -289,15 +291,40 @@ API void* comm_ar_create(int rank, int world, size_t max_bytes) {
     delete c;
     return nullptr;
   }
-  if (hipMalloc((void**)&c->local, total) != hipSuccess) {
+  // The peers poll this buffer's flags and read its data while kernels of this process write them:
+  // fine-grained memory is the allocation kind whose writes are visible to another device inside a
+  // running kernel.  Where the runtime cannot export such an allocation over IPC, fall back to an
+  // ordinary one (system-scope atomics and fences then carry the visibility, as before).
+  c->fine_grained = 0;
+  c->local = nullptr;
+  if (hipExtMallocWithFlags((void**)&c->local, total, hipDeviceMallocFinegrained) == hipSuccess) {
+    hipIpcMemHandle_t probe;
+    if (hipIpcGetMemHandle(&probe, c->local) == hipSuccess) {
+      c->fine_grained = 1;
+    } else {
+      (void)hipFree(c->local);
+      c->local = nullptr;
+    }
+  }
+  (void)hipGetLastError();
+  if (!c->local && hipMalloc((void**)&c->local, total) != hipSuccess) {
     delete c;
     return nullptr;
   }
   (void)hipMemset(c->local, 0, total);
   (void)hipMalloc((void**)&c->epochs, AR_BLOCKS * sizeof(uint32_t));
   (void)hipMemset(c->epochs, 0, AR_BLOCKS * sizeof(uint32_t));
-  (void)hipMalloc((void**)&c->err, sizeof(int));
-  (void)hipMemset(c->err, 0, sizeof(int));
+  c->err_host = nullptr;
+  c->err = nullptr;
+  if (hipHostMalloc((void**)&c->err_host, sizeof(int), hipHostMallocMapped) == hipSuccess &&
+      hipHostGetDevicePointer((void**)&c->err, c->err_host, 0) == hipSuccess) {
+    *c->err_host = 0;
+  } else {
+    if (c->err_host) (void)hipHostFree(c->err_host);
+    c->err_host = nullptr;
+    (void)hipMalloc((void**)&c->err, sizeof(int));
+    (void)hipMemset(c->err, 0, sizeof(int));
+  }
   (void)hipDeviceSynchronize();
   for (int r = 0; r < AR_MAX_RANKS; ++r) c->peers[r] = nullptr;
   c->peers[rank] = c->local;
@@ -346,10 +373,24 @@ API int comm_ar_allreduce_bf16(void* ctx, void* data, long n, void* stream) {
 // 1 if any call since creation gave up waiting for a peer (synchronises the device).
 API int comm_ar_failed(void* ctx) {
   bind_thread();
+  ArCtx* c = (ArCtx*)ctx;
   int v = 0;
-  (void)hipMemcpy(&v, ((ArCtx*)ctx)->err, sizeof(int), hipMemcpyDeviceToHost);
+  if (c->err_host) {
+    (void)hipDeviceSynchronize();
+    return *(volatile int*)c->err_host;
+  }
+  (void)hipMemcpy(&v, c->err, sizeof(int), hipMemcpyDeviceToHost);
   return v;
 }
+
+// The same word without touching the device: what the kernels that have FINISHED reported.  Cheap
+// enough for once per engine step (call it after the step's own read-back).  -1: not available.
+API int comm_ar_failed_nosync(void* ctx) {
+  ArCtx* c = (ArCtx*)ctx;
+  return c->err_host ? *(volatile int*)c->err_host : -1;
+}
+
+API int comm_ar_fine_grained(void* ctx) { return ((ArCtx*)ctx)->fine_grained; }
 
 API void comm_ar_destroy(void* ctx) {
   bind_thread();
@@ -358,6 +399,9 @@ API void comm_ar_destroy(void* ctx) {
     if (r != c->rank && c->peers[r]) (void)hipIpcCloseMemHandle(c->peers[r]);
   (void)hipFree(c->local);
   (void)hipFree(c->epochs);
-  (void)hipFree(c->err);
+  if (c->err_host)
+    (void)hipHostFree(c->err_host);
+  else
+    (void)hipFree(c->err);
   delete c;
 }

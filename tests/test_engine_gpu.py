@@ -45,21 +45,57 @@ def test_graph_and_eager_decode_agree(model):
     assert a == b
 
 
-def test_gpu_matches_cpu_reference_prefix():
-    """bf16 HIP path vs the fp32 PyTorch path on the same weights: the first generated tokens of
-    a greedy continuation agree (later ones may diverge after a near-tie; two is conservative)."""
-    ps = prompts(3, 150, seed=2)
-    g = gpu_engine("tiny-llama-gqa")
-    cpu = LLMEngine(EngineConfig(model="tiny-llama-gqa", device="cpu", dtype="float32",
+def _capture_logits(engine):
+    """Record the logits rows handed to the sampler at every step (fp32, on the host)."""
+    seen = []
+    orig = engine.runner.sampler.sample
+
+    def spy(logits, reqs, *a, **kw):
+        seen.append(logits[:len(reqs)].float().cpu())
+        return orig(logits, reqs, *a, **kw)
+
+    engine.runner.sampler.sample = spy
+    return seen
+
+
+@pytest.mark.parametrize("model", ["tiny-llama-gqa", "tiny-qwen2", "tiny-mixtral"])
+def test_gpu_matches_cpu_reference_logits(model):
+    """bf16 HIP path against the fp32 PyTorch path on the same weights, on EVERY prompt: the logits
+    of the last prompt position (the whole prefill: embedding, every layer's attention over the
+    paged cache, MLP / experts, final norm, LM head) have cosine similarity >= 0.999 with the fp32
+    ones and name the same token unless fp32 itself has a near-tie; the logits of the first decode
+    steps (HIP-graph path, reading the cache the prefill wrote) stay >= 0.998.  The mixture-of-experts
+    model gets a looser bound (0.97): its random router has near-ties between experts that bf16 and
+    fp32 resolve differently, and a token that takes another expert moves the logits more than any
+    rounding does (the same bf16 model run by PyTorch on the CPU is equally far from fp32).  Expert
+    kernels are pinned against fp32 at fixed routing in test_kernels_gpu.py."""
+    lo_prefill, lo_decode = (0.97, 0.96) if model == "tiny-mixtral" else (0.999, 0.998)
+    ps = prompts(6, 150, seed=2) + prompts(2, 700, seed=12)  # the long ones span several chunks and pages
+    g = gpu_engine(model, pages=160)
+    cpu = LLMEngine(EngineConfig(model=model, device="cpu", dtype="float32",
                                  max_model_len=2048, max_num_seqs=16, max_num_batched_tokens=512,
-                                 num_gpu_blocks_override=96, port=0))
+                                 num_gpu_blocks_override=160, port=0))
     # device generators differ from the CPU one: give the fp32 model the GPU model's weights
     for dst, src in zip(cpu.runner.model.weight_tensors(), g.runner.model.weight_tensors()):
         dst.copy_(src.float().cpu())
-    a = g.generate(ps, copy.deepcopy(SP))
-    b = cpu.generate(ps, copy.deepcopy(SP))
-    agree = sum(x[:2] == y[:2] for x, y in zip(a, b))
-    assert agree >= 2
+    cos = torch.nn.functional.cosine_similarity
+    sp = SamplingParams(max_tokens=4, temperature=0, ignore_eos=True)
+    for i, p in enumerate(ps):
+        lg, lc = _capture_logits(g), _capture_logits(cpu)
+        a = g.generate([p], copy.deepcopy(sp))[0]
+        b = cpu.generate([p], copy.deepcopy(sp))[0]
+        first_g, first_c = lg[-4][0], lc[-4][0]  # the step that sampled the first token
+        c0 = cos(first_g, first_c, dim=0).item()
+        assert c0 >= lo_prefill, (model, i, c0)
+        top2 = first_c.topk(2).values
+        if (top2[0] - top2[1]).item() > 0.05 * first_c.std().item():
+            assert a[0] == b[0], (model, i, a, b)
+        # decode steps: compare while both paths condition on the same tokens
+        for step in range(1, 4):
+            if a[:step] != b[:step]:
+                break
+            cs = cos(lg[-4 + step][0], lc[-4 + step][0], dim=0).item()
+            assert cs >= lo_decode, (model, i, step, cs)
 
 
 def test_graph_replay_survives_allocator_churn():

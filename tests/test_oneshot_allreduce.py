@@ -61,10 +61,10 @@ def _rank(rank, world, q_in, q_out, result):
             if not bool((buf.float() == expect).all()):
                 ok, detail = False, f"graph replay {k}: got {buf[:4].tolist()}, want {expect}"
                 break
-    failed = ar.failed()
+    failed = ar.failed() or ar.failed_nosync()  # the second reads the pinned host word: no device sync
     big = torch.zeros(4 << 20, dtype=torch.bfloat16, device=dev)
     fits_big = ar.fits(big)
-    result.put((rank, ok and not failed and not fits_big, detail or f"failed={failed} fits_big={fits_big}"))
+    result.put((rank, ok and not failed and not fits_big, detail or f"failed={failed} fits_big={fits_big} fine_grained={ar.fine_grained}"))
     q_in.get(timeout=60)  # hold the mapping until every rank is done
     ar.close()
 

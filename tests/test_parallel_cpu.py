@@ -119,3 +119,35 @@ def test_layer_ranges_cover_model():
             spans = [PPGroup(rank=r, size=size).layer_range(layers) for r in range(size)]
             assert spans[0][0] == 0 and spans[-1][1] == layers
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_a_timed_out_one_shot_all_reduce_fails_the_step_and_falls_back():
+    """The per-step check: a one-shot all-reduce that gave up waiting for a peer left its operand
+    unreduced; the step must fail loudly, and the kernel must not be used again."""
+    import pytest
+    from vllm_production_stack_amd.parallel import state
+
+    class Stub:
+        def __init__(self):
+            self.bad, self.closed = False, False
+
+        def failed_nosync(self):
+            return self.bad
+
+        def close(self):
+            self.closed = True
+
+    tp = state.get_tp()
+    old = tp.oneshot
+    stub = Stub()
+    tp.oneshot = stub
+    try:
+        state.check_collectives()  # healthy: nothing happens
+        assert tp.oneshot is stub
+        stub.bad = True
+        with pytest.raises(RuntimeError, match="all-reduce timed out"):
+            state.check_collectives()
+        assert tp.oneshot is None and stub.closed
+        state.check_collectives()  # and the next step runs (over RCCL)
+    finally:
+        tp.oneshot = old

@@ -26,7 +26,7 @@ import torch
 from .. import ops
 from ..models.batch import BatchMeta
 from ..models.loader import build_model
-from ..parallel.state import (get_pp, get_replica, get_tp, pp_recv, pp_send, replica_broadcast,
+from ..parallel.state import (check_collectives, get_pp, get_replica, get_tp, pp_recv, pp_send, replica_broadcast,
                               replica_min_int)
 from .block_manager import PAGE
 from .config import EngineConfig, ModelConfig
@@ -259,6 +259,8 @@ class ModelRunner:
             if s.req.pooling:
                 s.req.pooled = hidden[i].float().cpu()
         toks, infos = self.sampler.sample(logits, [s.req for s in sample_seqs])
+        if self.distributed:
+            check_collectives()  # the sampled tokens are on the host: every kernel of the step has run
         return list(zip(sample_seqs, toks, infos))
 
     # ------------------------------------------------------------------ worker ranks
@@ -274,6 +276,10 @@ class ModelRunner:
                     return
                 if kind == "step":
                     self._run_plan(msg[1])
+                    try:
+                        check_collectives()  # lags a step on worker ranks (they never read back)
+                    except RuntimeError as e:
+                        log.error("%s", e)
                 elif kind == "sleep":
                     self._sleep_local(msg[1])
                 elif kind == "wake":

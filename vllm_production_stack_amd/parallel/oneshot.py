@@ -38,6 +38,8 @@ def _comm():
         lib.comm_ar_allreduce_bf16.argtypes = [c_void_p, c_void_p, c_long, c_void_p]
         lib.comm_ar_failed.restype = c_int
         lib.comm_ar_failed.argtypes = [c_void_p]
+        lib.comm_ar_failed_nosync.argtypes = [c_void_p]
+        lib.comm_ar_fine_grained.argtypes = [c_void_p]
         lib.comm_ar_destroy.argtypes = [c_void_p]
         _lib = lib
     return _lib
@@ -82,6 +84,17 @@ class OneShotAllReduce:
     def failed(self) -> bool:
         """True if a call gave up waiting for a peer (synchronises the device)."""
         return bool(self.lib.comm_ar_failed(self.ctx))
+
+    def failed_nosync(self) -> bool:
+        """What the all-reduce kernels that have already finished reported, read from pinned host
+        memory: no device synchronisation, meant to be called once per engine step after the
+        step's own read-back."""
+        v = int(self.lib.comm_ar_failed_nosync(self.ctx))
+        return self.failed() if v < 0 else bool(v)
+
+    @property
+    def fine_grained(self) -> bool:
+        return bool(self.lib.comm_ar_fine_grained(self.ctx))
 
     def close(self) -> None:
         if self.ctx:

@@ -166,6 +166,22 @@ def enable_oneshot_all_reduce(device: torch.device, max_bytes: int = 4 << 20) ->
     return True
 
 
+def check_collectives() -> None:
+    """Once per engine step, after the step's read-back: did a one-shot all-reduce of the steps
+    finished so far give up waiting for a peer?  Its operand was then left unreduced, so what
+    was sampled from it is garbage: fail the step, and stop using the one-shot kernel so that
+    the following steps go through RCCL (the peers follow when their own waits time out)."""
+    tp = _TP
+    if tp.oneshot is not None and tp.oneshot.failed_nosync():
+        one, tp.oneshot = tp.oneshot, None
+        try:
+            one.close()
+        except Exception:
+            pass
+        raise RuntimeError("tensor-parallel all-reduce timed out waiting for a peer rank; "
+                           "one-shot all-reduce disabled, falling back to RCCL")
+
+
 def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
     tp = _TP
     if tp.size == 1:
