@@ -129,8 +129,10 @@ class LocalStack:
         self.procs: list[tuple[ProcessSpec, subprocess.Popen]] = []
 
     def start(self, ready_timeout: float = 600.0) -> None:
-        order = {"cache-server": 0, "engine": 1, "router": 2}
-        for spec in sorted(self.plan, key=lambda s: order[s.role]):
+        """Cache servers and engines start together (engines of one GPU set size their pools from
+        free memory, so they come up one after another there); the router starts once every
+        engine answers /health, so its first scrape finds all of them."""
+        def launch(spec: ProcessSpec) -> None:
             env = {**os.environ, **spec.env}
             out = None
             if self.log_dir:
@@ -139,12 +141,23 @@ class LocalStack:
             p = subprocess.Popen(spec.argv, env=env, stdout=out, stderr=subprocess.STDOUT if out else None,
                                  start_new_session=True)
             self.procs.append((spec, p))
-        for spec, p in self.procs:
-            if spec.role == "cache-server":
-                continue
+
+        def healthy(spec: ProcessSpec) -> None:
             if not _wait_http(f"http://127.0.0.1:{spec.port}/health", ready_timeout):
                 self.stop()
                 raise RuntimeError(f"{spec.name} did not become healthy on port {spec.port}")
+
+        for role in ("cache-server", "engine"):
+            for spec in self.plan:
+                if spec.role == role:
+                    launch(spec)
+        for spec in self.plan:
+            if spec.role == "engine":
+                healthy(spec)
+        for spec in self.plan:
+            if spec.role == "router":
+                launch(spec)
+                healthy(spec)
 
     def stop(self) -> None:
         for _spec, p in reversed(self.procs):

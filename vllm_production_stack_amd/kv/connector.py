@@ -66,7 +66,15 @@ class KVConnector:
         if off.local_cpu or off.max_local_cpu_gb > 0:
             cap = int((off.max_local_cpu_gb or 5.0) * (1 << 30))
             self.host = HostKVPool(self.pool, cap, on_spill=self._spill)
+            log.info("host KV tier: %d slots of %.1f MiB (%.1f GiB%s)", self.host.n_slots,
+                     self.host.page_bytes / (1 << 20), self.host.n_slots * self.host.page_bytes / (1 << 30),
+                     " pinned" if self.pool.is_cuda else "")
+        if self.disk is not None:
+            log.info("disk KV tier: %.1f GiB under %s", off.max_local_disk_gb, self.disk.root
+                     if hasattr(self.disk, "root") else off.local_disk_path)
         self.remote = RemoteKVClient(off.remote_url) if off.remote_url else None
+        if self.remote is not None:
+            log.info("remote KV tier: %s (keys under %s/)", off.remote_url, self.namespace)
         self.cfg_remote_url = off.remote_url
         self.remote_known: set[int] = set()
         self.remote_dropped = 0  # fresh pages given up on because the server stopped draining the ring
