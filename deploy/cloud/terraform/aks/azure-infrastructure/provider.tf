@@ -1,0 +1,14 @@
+terraform {
+  required_version = ">= 1.5"
+  required_providers {
+    azurerm = { source = "hashicorp/azurerm", version = "~> 3.110" }
+    local   = { source = "hashicorp/local", version = "~> 2.5" }
+  }
+}
+
+provider "azurerm" {
+  features {
+    resource_group { prevent_deletion_if_contains_resources = false }
+  }
+  subscription_id = var.subscription_id
+}

@@ -314,3 +314,42 @@ def test_tutorials_reference_existing_files():
     index = (tut / "README.md").read_text()
     for page in pages:
         assert page.name == "README.md" or f"({page.name})" in index, f"{page.name} is not linked from the index"
+
+
+CLOUD = ROOT / "deploy" / "cloud"
+
+
+@pytest.mark.parametrize("path", sorted(CLOUD.glob("**/production_stack_specification.yaml")),
+                         ids=lambda p: "-".join(p.relative_to(CLOUD).parts[:-1]))
+def test_cloud_values_render_with_the_chart(path):
+    """The values the cloud bring-up scripts install: eight GPU replicas on the labelled pool, the
+    storage class of that cloud, a multi-worker prefix-aware router."""
+    objs = _objs(path)
+    dep = next(o for o in objs if o["kind"] == "Deployment" and o["metadata"]["name"] == "vllm-llama3-deployment-vllm")
+    assert dep["spec"]["replicas"] == 8
+    c = dep["spec"]["template"]["spec"]["containers"][0]
+    assert c["resources"]["limits"]["amd.com/gpu"] in (1, "1")
+    pvc = next(o for o in objs if o["kind"] == "PersistentVolumeClaim")
+    assert pvc["spec"]["storageClassName"] in ("efs-sc", "managed-csi-premium", "premium-rwo")
+    router = next(o for o in objs if o["kind"] == "Deployment" and o["metadata"]["name"] == "vllm-deployment-router")
+    rc = router["spec"]["template"]["spec"]["containers"][0]
+    args = rc.get("args") or rc.get("command")
+    assert "--router-workers" in args and "prefixaware" in args
+
+
+def test_cloud_scripts_parse_and_share_the_common_tail():
+    import subprocess
+
+    scripts = sorted(CLOUD.glob("**/*.sh"))
+    assert {p.parent.name for p in scripts} >= {"aws", "azure", "gcp", "common"}
+    for p in scripts:
+        r = subprocess.run(["bash", "-n", str(p)], capture_output=True, text=True)
+        assert r.returncode == 0, (p, r.stderr)
+    for cloud in ("aws", "azure", "gcp"):
+        text = (CLOUD / cloud / "entry_point.sh").read_text()
+        for step in ("need ", "wait_nodes_ready", "install_stack", "smoke_test", "uninstall_stack" if cloud != "aws" else "clean_up.sh"):
+            assert step in text, (cloud, step)
+    # every Terraform root module declares its providers and formats as HCL blocks that balance
+    for tf in CLOUD.glob("terraform/**/*.tf"):
+        body = tf.read_text()
+        assert body.count("{") == body.count("}"), tf
