@@ -488,7 +488,14 @@ async def initialize_all(state: RouterState) -> None:
     if gates.is_enabled("PIIDetection"):
         from .pii import PIIConfig, PIIGuard
 
-        state.pii_guard = PIIGuard(PIIConfig(enabled=True, analyzer=args.pii_analyzer))
+        from .pii import PIIType
+
+        pii_cfg = json.loads(args.pii_analyzer_config) if getattr(args, "pii_analyzer_config", "") else {}
+        pii_cfg.setdefault("fallback", "regex")  # a missing optional package must not stop the router
+        pii_types = {PIIType(t.strip()) for t in getattr(args, "pii_types", "").split(",") if t.strip()} or None
+        state.pii_guard = PIIGuard(PIIConfig(enabled=True, analyzer=args.pii_analyzer, types=pii_types,
+                                             score_threshold=getattr(args, "pii_score_threshold", 0.5),
+                                             analyzer_config=pii_cfg))
         logger.info("PII detection enabled (%s analyzer)", args.pii_analyzer)
 
 

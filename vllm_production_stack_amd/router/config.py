@@ -115,7 +115,12 @@ def build_parser() -> argparse.ArgumentParser:
       help="retry a request on another endpoint when the chosen one refuses the connection")
     a("--prefix-trie-max-nodes", type=int, default=4_000_000,
       help="node budget of the prefix-aware trie (0 = unbounded)")
-    a("--pii-analyzer", default="regex", choices=["regex", "presidio"])
+    a("--pii-analyzer", default="regex",
+      help="regex | presidio | package.module:Class (a PIIAnalyzer subclass)")
+    a("--pii-analyzer-config", default="",
+      help="JSON object handed to the analyzer, e.g. '{\"spacy_model\": \"en_core_web_lg\", \"fallback\": \"regex\"}'")
+    a("--pii-types", default="", help="comma-separated types to look for (default: all the analyzer knows)")
+    a("--pii-score-threshold", type=float, default=0.5)
     a("--router-workers", type=int, default=1,
       help="router processes sharing the listening port (SO_REUSEPORT); the prefix trie and the "
            "round-robin position are shared between them")
