@@ -58,7 +58,19 @@ def _capture_logits(engine):
     return seen
 
 
-@pytest.mark.parametrize("model", ["tiny-llama-gqa", "tiny-qwen2", "tiny-mixtral"])
+def test_heads_of_64_channels_take_the_hip_kernels_and_graphs():
+    """OPT-125m / GPT-2 / Llama-3.2-1B geometry: the pool stores heads padded to 128 channels so that
+    the MFMA attention kernels and HIP-graph decode run instead of per-sequence PyTorch attention."""
+    for model in ("tiny-opt-hd64", "tiny-llama-hd64"):
+        eng = gpu_engine(model)
+        assert eng.runner.kv_head_dim == 128 and eng.runner.use_graphs
+        assert eng.runner.pool.shape[-1] == 64 * 128
+        ps = prompts(4, 200, seed=8)
+        assert eng.generate(ps, copy.deepcopy(SP)) == gpu_engine(model, enforce_eager=True).generate(ps, copy.deepcopy(SP))
+        assert eng.runner._graphs, "decode steps must have been captured"
+
+
+@pytest.mark.parametrize("model", ["tiny-llama-gqa", "tiny-qwen2", "tiny-mixtral", "tiny-opt-hd64", "tiny-llama-hd64"])
 def test_gpu_matches_cpu_reference_logits(model):
     """bf16 HIP path against the fp32 PyTorch path on the same weights, on EVERY prompt: the logits
     of the last prompt position (the whole prefill: embedding, every layer's attention over the
@@ -239,16 +251,20 @@ def test_speech_model_bf16_tracks_fp32_on_gpu():
     assert all(tok < cfg.eos_token_id for x in toks for tok in x)
 
 
-def test_opt_head_dim_64_runs_on_the_generic_attention_path():
-    """OPT-125m class models (head_dim 64) are outside the HIP attention kernels' shape: on a GPU
-    they take the PyTorch attention definitions, eagerly (no graphs), and must still serve."""
+def test_opt_125m_serves_on_the_hip_kernels_and_other_head_sizes_on_the_generic_path():
+    """OPT-125m (head_dim 64) runs the MFMA attention kernels with padded heads and HIP-graph
+    decode; a head size the kernels do not cover (32) takes the PyTorch attention definitions,
+    eagerly, and must still serve."""
     from vllm_production_stack_amd.engine.config import EngineConfig
     from vllm_production_stack_amd.engine.llm_engine import LLMEngine
     from vllm_production_stack_amd.engine.request import SamplingParams
 
     eng = LLMEngine(EngineConfig(model="opt-125m", max_model_len=1024, max_num_seqs=4,
                                  num_gpu_blocks_override=32))
-    assert not eng.runner.use_graphs
+    assert eng.runner.use_graphs and eng.runner.kv_head_dim == 128
+    small = LLMEngine(EngineConfig(model="tiny-opt", max_model_len=1024, max_num_seqs=4, num_gpu_blocks_override=32))
+    assert not small.runner.use_graphs and small.runner.kv_head_dim == 32
+    assert all(len(o) == 4 for o in small.generate([[5, 6, 7] * 20], SamplingParams(max_tokens=4, temperature=0, ignore_eos=True)))
     g = torch.Generator().manual_seed(0)
     prompts = [torch.randint(16, 5000, (n,), generator=g).tolist() for n in (130, 7)]
     outs = eng.generate(prompts, SamplingParams(max_tokens=6, temperature=0, ignore_eos=True))

@@ -136,6 +136,13 @@ PRESETS: dict[str, ModelConfig] = {
     "tiny-mixtral": ModelConfig(name="tiny-mixtral", architecture="mixtral", num_heads=4,
                                 num_kv_heads=2, hidden_size=256, intermediate_size=256,
                                 num_experts=4, num_experts_per_tok=2),
+    # heads of 64 channels (the geometry of OPT-125m, GPT-2, Llama-3.2-1B, Qwen2-0.5B)
+    "tiny-opt-hd64": ModelConfig(name="tiny-opt-hd64", architecture="opt", vocab_size=512, hidden_size=256,
+                                 intermediate_size=512, ffn_dim=512, num_layers=2, num_heads=4,
+                                 num_kv_heads=4, head_dim=64, pos_offset=2, tie_word_embeddings=True,
+                                 max_position_embeddings=2048),
+    "tiny-llama-hd64": ModelConfig(name="tiny-llama-hd64", num_heads=8, num_kv_heads=2, head_dim=64,
+                                   hidden_size=512, intermediate_size=1024, num_layers=3),
     "tiny-opt": ModelConfig(name="tiny-opt", architecture="opt", vocab_size=512, hidden_size=128,
                             intermediate_size=256, ffn_dim=256, num_layers=2, num_heads=4,
                             num_kv_heads=4, head_dim=32, pos_offset=2, tie_word_embeddings=True,

@@ -59,18 +59,20 @@ class ModelRunner:
         self.distributed = self.replica.size > 1
         # layers whose KV this rank holds (its pipeline stage)
         self.n_layers_local = len(self.model.layers)
-        self.page_elems = self.n_layers_local * 2 * self.n_kv_local * PAGE * model_cfg.head_dim
+        # channels per head as stored in the pool (heads of 64 are padded to the kernels' 128 on a GPU)
+        self.kv_head_dim = ops.kv_head_dim(model_cfg.head_dim, device)
+        self.page_elems = self.n_layers_local * 2 * self.n_kv_local * PAGE * self.kv_head_dim
         self.page_bytes = self.page_elems * torch.empty((), dtype=self.dtype).element_size()
         self.max_pages_per_seq = (self.max_model_len + PAGE - 1) // PAGE
         self.num_pages = self._plan_pages()
         self.pool = torch.zeros(
-            (self.num_pages, self.n_layers_local, 2, self.n_kv_local, PAGE * model_cfg.head_dim),
+            (self.num_pages, self.n_layers_local, 2, self.n_kv_local, PAGE * self.kv_head_dim),
             dtype=self.dtype, device=device)
         self.sampler = Sampler(device, cfg.seed)
         # collectives and stage hand-offs run eagerly: graphs only for single-process replicas
         # graphs need the HIP attention kernels (the generic path reads lengths on the host)
         self.use_graphs = (device.type == "cuda" and not cfg.enforce_eager and not self.distributed
-                           and model_cfg.head_dim == ops.HEAD_DIM_HIP)
+                           and self.kv_head_dim == ops.HEAD_DIM_HIP)
         self._graphs: dict[int, dict] = {}
         self._graph_pool = None
         self._pin = device.type == "cuda"
@@ -353,7 +355,7 @@ class ModelRunner:
         }
         splits = ops.decode_num_splits(bsz, self.n_kv_local, self.max_model_len)
         mc = self.model_cfg
-        ws_o = torch.empty((bsz, self.model.n_q, splits, mc.head_dim), dtype=torch.float32, device=dev)
+        ws_o = torch.empty((bsz, self.model.n_q, splits, self.kv_head_dim), dtype=torch.float32, device=dev)
         ws_ml = torch.empty((bsz, self.model.n_q, splits, 2), dtype=torch.float32, device=dev)
         meta = BatchMeta(positions=st["pos"], slots=st["slots"], num_decode=bsz,
                          dec_block_tables=st["bt"], dec_ctx_lens=st["ctx"], dec_num_splits=splits,

@@ -47,7 +47,7 @@ class KVConnector:
         mc = engine.model_cfg
         self.pool = r.pool
         self.device = r.device
-        self.serde = PageSerde(mc.num_layers, r.n_kv_local, mc.head_dim, r.dtype, off.remote_serde)
+        self.serde = PageSerde(mc.num_layers, r.n_kv_local, r.kv_head_dim, r.dtype, off.remote_serde)
         # Pages of the lower tiers are keyed by the token chain hash, which says nothing about the
         # weights that produced them.  Everything that leaves this process (remote server keys,
         # disk files) is therefore namespaced by the model identity and the shard of it this rank
@@ -61,7 +61,7 @@ class KVConnector:
 
             self.disk = DiskKVStore(os.path.join(off.local_disk_path, self.namespace),
                                     int(off.max_local_disk_gb * (1 << 30)),
-                                    PageSerde(mc.num_layers, r.n_kv_local, mc.head_dim, r.dtype, "naive"))
+                                    PageSerde(mc.num_layers, r.n_kv_local, r.kv_head_dim, r.dtype, "naive"))
         self.host = None
         if off.local_cpu or off.max_local_cpu_gb > 0:
             cap = int((off.max_local_cpu_gb or 5.0) * (1 << 30))
@@ -121,7 +121,7 @@ class KVConnector:
         tp, pp = get_tp(), get_pp()
         ident = "|".join(str(x) for x in (
             engine.cfg.model, engine.cfg.model_name, runner.dtype, mc.num_layers, mc.hidden_size,
-            mc.head_dim, f"tp{tp.rank}of{tp.size}", f"pp{pp.rank}of{pp.size}",
+            runner.kv_head_dim if hasattr(runner, "kv_head_dim") else mc.head_dim, f"tp{tp.rank}of{tp.size}", f"pp{pp.rank}of{pp.size}",
             getattr(engine.cfg, "kv_namespace", "") or ""))
         return hashlib.sha1(ident.encode()).hexdigest()[:12]
 

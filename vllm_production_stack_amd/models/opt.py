@@ -83,17 +83,7 @@ class OPTModel:
         for li, lw in enumerate(self.layers):
             x = reference.layer_norm(h, lw["ln1_w"], lw["ln1_b"], 1e-5)
             qkv = F.linear(x, lw["wqkv"], lw["bqkv"])
-            ops.rope_and_cache(qkv, meta.positions, meta.slots, self.cos_sin, pool, li, nq, nkv, d,
-                               rotary=False)
-            out = torch.empty((qkv.shape[0], nq * d), dtype=qkv.dtype, device=qkv.device)
-            q = qkv[:, : nq * d]
-            if nd > 0:
-                ops.paged_decode(q[:nd], out[:nd], pool, li, meta.dec_block_tables,
-                                 meta.dec_ctx_lens, nq, nkv, d, self.scale)
-            if meta.num_prefill_seqs > 0:
-                ops.paged_prefill(q[nd:], out[nd:], pool, li, meta.pre_block_tables, meta.pre_cu_q,
-                                  meta.pre_ctx_lens, meta.pre_tile_seq, meta.pre_tile_q0, nq, nkv,
-                                  d, self.scale, meta.pre_tile_rows)
+            out = ops.attention_block(qkv, pool, li, meta, nq, nkv, d, self.scale, self.cos_sin, rotary=False)
             h = h + F.linear(out, lw["wo"], lw["bo"])
             x = reference.layer_norm(h, lw["ln2_w"], lw["ln2_b"], 1e-5)
             a = F.linear(x, lw["fc1"], lw["b1"])

@@ -156,23 +156,8 @@ class TransformerModel:
 
     # ------------------------------------------------------------------ forward
     def _attention(self, qkv: torch.Tensor, pool: torch.Tensor, layer: int, meta: BatchMeta):
-        cfg = self.cfg
-        nq, nkv, d = self.n_q, self.n_kv, self.head_dim
-        ops.rope_and_cache(qkv, meta.positions, meta.slots, self.cos_sin, pool, layer, nq, nkv, d)
-        t = qkv.shape[0]
-        out = torch.empty((t, nq * d), dtype=qkv.dtype, device=qkv.device)
-        nd = meta.num_decode
-        q = qkv[:, : nq * d]
-        if nd > 0:
-            ops.paged_decode(q[:nd], out[:nd], pool, layer, meta.dec_block_tables,
-                             meta.dec_ctx_lens, nq, nkv, d, self.scale, meta.dec_num_splits,
-                             meta.dec_ws_o, meta.dec_ws_ml)
-        if meta.num_prefill_seqs > 0:
-            ops.paged_prefill(q[nd:], out[nd:], pool, layer, meta.pre_block_tables, meta.pre_cu_q,
-                              meta.pre_ctx_lens, meta.pre_tile_seq, meta.pre_tile_q0, nq, nkv, d,
-                              self.scale, meta.pre_tile_rows)
-        del cfg
-        return out
+        return ops.attention_block(qkv, pool, layer, meta, self.n_q, self.n_kv, self.head_dim, self.scale,
+                                   self.cos_sin, rotary=True)
 
     def _moe(self, x: torch.Tensor, lw: LayerWeights, decode_only: bool) -> torch.Tensor:
         cfg = self.cfg

@@ -127,9 +127,9 @@ def rms_norm(x, weight, eps, residual=None, out=None):
 
 # --------------------------------------------------------------------------- rope + cache write
 def _generic_attention(t, head_dim) -> bool:
-    """The HIP attention kernels are built for head_dim 128 (Llama-3, Mixtral).  Other head
-    sizes on a GPU (OPT-125m class test models) take the PyTorch definitions: correct, slow,
-    and announced once, never chosen for a model the kernels cover."""
+    """The HIP attention kernels are built for head_dim 128 (Llama-3, Mixtral); heads of 64
+    channels reach them padded (``kv_head_dim``).  Any other head size on a GPU takes the PyTorch
+    definitions: correct, slow, announced once, never chosen for a model the kernels cover."""
     global _warned_generic
     if not t.is_cuda:
         return True
@@ -146,6 +146,58 @@ def _generic_attention(t, head_dim) -> bool:
 
 
 _warned_generic = False
+
+# Heads of 64 channels (OPT, GPT-2, Llama-3.2-1B, Qwen2-0.5B) run on the head_dim-128 kernels with
+# their channels zero-padded in the KV cache and in Q: zero channels add nothing to QK^T, and the
+# padded half of the output is dropped.  Costs twice the KV bytes of those (small) models and buys
+# the MFMA kernels and HIP-graph decode instead of per-sequence PyTorch attention.
+PAD_HEAD_64 = os.environ.get("VPSA_PAD_HEAD64", "1") != "0"
+
+
+def kv_head_dim(head_dim: int, device) -> int:
+    """Channels per head as stored in the KV pool of a replica on ``device``."""
+    if PAD_HEAD_64 and head_dim == 64 and torch.device(device).type == "cuda":
+        return HEAD_DIM_HIP
+    return head_dim
+
+
+_pad_cos_sin: dict = {}
+
+
+def attention_block(qkv, pool, layer, meta, n_q, n_kv, head_dim, scale, cos_sin, rotary=True):
+    """Rotary embedding, KV-cache write and paged attention of one layer for a mixed batch
+    (``meta.num_decode`` decode rows first, then the prefill rows).  qkv [T, (n_q + 2 n_kv) * d];
+    returns the attention output [T, n_q * d]."""
+    t = qkv.shape[0]
+    d = head_dim
+    dk = kv_head_dim(d, qkv.device)
+    if dk != d:
+        # rotate at the true width, then widen every head with zero channels
+        if rotary:
+            reference.rope_and_cache(qkv, meta.positions, None, cos_sin, pool, layer, n_q, n_kv, d, True)
+        wide = torch.nn.functional.pad(qkv.view(t, n_q + 2 * n_kv, d), (0, dk - d)).view(t, -1)
+        cs = _pad_cos_sin.get(qkv.device)
+        if cs is None:
+            cs = _pad_cos_sin[qkv.device] = torch.zeros((1, dk), dtype=torch.float32, device=qkv.device)
+        out = _attention_block(wide, pool, layer, meta, n_q, n_kv, dk, scale, cs, False)
+        return out.view(t, n_q, dk)[:, :, :d].reshape(t, n_q * d)
+    return _attention_block(qkv, pool, layer, meta, n_q, n_kv, d, scale, cos_sin, rotary)
+
+
+def _attention_block(qkv, pool, layer, meta, n_q, n_kv, d, scale, cos_sin, rotary):
+    rope_and_cache(qkv, meta.positions, meta.slots, cos_sin, pool, layer, n_q, n_kv, d, rotary)
+    t = qkv.shape[0]
+    out = torch.empty((t, n_q * d), dtype=qkv.dtype, device=qkv.device)
+    nd = meta.num_decode
+    q = qkv[:, : n_q * d]
+    if nd > 0:
+        paged_decode(q[:nd], out[:nd], pool, layer, meta.dec_block_tables, meta.dec_ctx_lens, n_q, n_kv, d,
+                     scale, getattr(meta, "dec_num_splits", 1) or 1, getattr(meta, "dec_ws_o", None),
+                     getattr(meta, "dec_ws_ml", None))
+    if meta.num_prefill_seqs > 0:
+        paged_prefill(q[nd:], out[nd:], pool, layer, meta.pre_block_tables, meta.pre_cu_q, meta.pre_ctx_lens,
+                      meta.pre_tile_seq, meta.pre_tile_q0, n_q, n_kv, d, scale, meta.pre_tile_rows)
+    return out
 
 
 def rope_and_cache(qkv, positions, slots, cos_sin, pool, layer, n_q, n_kv, head_dim, rotary=True):
