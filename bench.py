@@ -89,6 +89,11 @@ def parse() -> argparse.Namespace:
                     help="rounds of the second phase in the reference's own configuration (0 = skip)")
     ap.add_argument("--reference-users-per-gpu", type=int, default=15)
     ap.add_argument("--reference-offload-gb", type=float, default=45.0)
+    ap.add_argument("--open-loop-seconds", type=int, default=30,
+                    help="after the rounds of the reference-configuration phase: the reference's own "
+                         "open-loop procedure (QPS-paced arrivals, users joining over time) for this long; 0 = skip")
+    ap.add_argument("--open-loop-qps-per-gpu", type=float, default=1.1,
+                    help="offered request rate per replica (1.1 is the top of the reference's single-GPU sweep)")
     ap.add_argument("--base-port", type=int, default=_default_base_port())
     ap.add_argument("--clients", type=int, default=0, help="load-generator processes (0 = auto)")
     ap.add_argument("--device", default="cuda", help="cpu runs a plumbing rehearsal (tiny models)")
@@ -176,6 +181,48 @@ def spawn_children(a: argparse.Namespace, n: int, port0: int, routing: str, user
     return router, clients, workers
 
 
+def run_open_loop_client(a: argparse.Namespace, port0: int, n: int, spec: dict) -> dict:
+    """One point of the reference's QPS sweep (benchmarks/multi_round_qa/multi_round_qa.py is the
+    same tool the sweep script drives), as a child process; returns its summary."""
+    import csv
+    import io
+    import tempfile
+
+    sys.path.insert(0, os.path.join(ROOT, "benchmarks", "multi_round_qa"))
+    import multi_round_qa as mrq
+
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "HIP_VISIBLE_DEVICES"):
+        env.pop(k, None)
+    out = os.path.join(tempfile.mkdtemp(prefix="vpsa-bench-"), "open_loop.csv")
+    qps = spec["qps_per_gpu"] * n
+    cmd = [sys.executable, os.path.join(ROOT, "benchmarks", "multi_round_qa", "multi_round_qa.py"),
+           "--num-users", str(spec["users_per_gpu"] * n), "--num-rounds", str(spec["rounds"]),
+           "--qps", str(qps), "--shared-system-prompt", str(a.sys_len),
+           "--user-history-prompt", str(a.history_len), "--answer-len", str(a.answer_len),
+           "--model", a.model, "--base-url", f"http://127.0.0.1:{port0}", "--time", str(spec["seconds"]),
+           "--init-user-id", str(spec["user_base"]), "--request-with-user-id", "--output", out,
+           "--log-interval", "1000"]
+    t0 = time.time()
+    proc = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                          timeout=spec["seconds"] + 300)
+    if proc.returncode != 0:
+        return {"error": proc.stderr[-500:]}
+    with open(out) as f:
+        rows = [{k: float(v) for k, v in r.items()} for r in csv.DictReader(f)]
+    s = mrq.summarize(rows, out=io.StringIO())
+    if not s:
+        return {"error": "no finished requests"}
+    return {"what": "open loop, the reference's procedure: requests paced at a fixed rate, sessions pre-aged, "
+                    "new users joining; mean TTFT at this rate is the reference's headline metric",
+            "offered_qps": qps, "users": spec["users_per_gpu"] * n, "seconds": spec["seconds"],
+            "wall_s": round(time.time() - t0, 1), "requests": s["requests"],
+            "finished_qps": round(s["finished_qps"], 3), "mean_ttft_s": round(s["mean_ttft_s"], 4),
+            "p50_ttft_s": round(s["p50_ttft_s"], 4), "p90_ttft_s": round(s["p90_ttft_s"], 4),
+            "output_tok_per_s": round(s["output_tokens_per_s"], 1),
+            "generation_tok_per_s_per_request": round(s["avg_generation_speed_per_request"], 1)}
+
+
 def wait_line(p: subprocess.Popen, prefix: str) -> str:
     while True:
         line = p.stdout.readline()
@@ -199,7 +246,8 @@ def stop_children(procs) -> None:
 
 
 async def run_phase(a, ctx, *, port0: int, routing: str, users_per_gpu: int, warm_users_per_gpu: int,
-                    rounds: int, warm_rounds: int, user_base: int, engine_kwargs: dict) -> dict | None:
+                    rounds: int, warm_rounds: int, user_base: int, engine_kwargs: dict,
+                    open_loop: dict | None = None) -> dict | None:
     """One measured phase: engine up, children up, warm-up, the timed rounds, everything down again
     (router and load generators first, so nothing scrapes an engine that is already gone).
     Returns the result dictionary on rank 0."""
@@ -288,6 +336,18 @@ async def run_phase(a, ctx, *, port0: int, routing: str, users_per_gpu: int, war
             elapsed = float(t.item())
             per_replica = [None] * world
             dist.all_gather_object(per_replica, mine, group=gloo)
+        kv_tiers = ({"host_loads_pages": conn.host.loads, "host_stores_pages": conn.host.stores,
+                     "host_evictions_pages": conn.host.evictions, "host_slots": conn.host.n_slots}
+                    if conn is not None and conn.host is not None else None)
+        prof_delta = {k: (round(v - prof0.get(k, 0), 3) if isinstance(v, float) else v - prof0.get(k, 0))
+                      for k, v in engine.prof.items()}
+        open_loop_result = None
+        if open_loop:
+            # the reference's procedure against the same stack: requests arrive at a fixed rate,
+            # sessions are pre-aged and new users keep joining (multi-round-qa.py's main loop)
+            if rank == 0:
+                open_loop_result = await loop.run_in_executor(None, run_open_loop_client, a, port0, n, open_loop)
+            await loop.run_in_executor(None, barrier)
         if rank != 0:
             return None
 
@@ -310,13 +370,9 @@ async def run_phase(a, ctx, *, port0: int, routing: str, users_per_gpu: int, war
             "p50_ttft_warm_rounds_s": round(mrq.pct(warm, 0.5), 4) if warm else None,
             "p50_ttft_cold_round_s": round(mrq.pct(cold, 0.5), 4) if cold else None,
             "round_times_s": [round(x, 3) for x in outs[0]["round_times"]] if outs else [],
-            "per_replica": per_replica, "router_workers": workers,
+            "per_replica": per_replica, "router_workers": workers, "open_loop": open_loop_result,
             "kv_pages_per_replica": engine.runner.num_pages,
-            "kv_tiers": ({"host_loads_pages": conn.host.loads, "host_stores_pages": conn.host.stores,
-                          "host_evictions_pages": conn.host.evictions, "host_slots": conn.host.n_slots}
-                         if conn is not None and conn.host is not None else None),
-            "engine0_profile": {k: (round(v - prof0.get(k, 0), 3) if isinstance(v, float) else v - prof0.get(k, 0))
-                                for k, v in engine.prof.items()},
+            "kv_tiers": kv_tiers, "engine0_profile": prof_delta,
         }
     finally:
         # order matters for a clean log: the router (rank 0) goes first, every rank waits for that,
@@ -391,7 +447,10 @@ async def rank_main(a: argparse.Namespace) -> None:
                                        enable_prefix_caching=False, enable_chunked_prefill=False,
                                        prefill_step_ms=0.0,
                                        kv_offload=KVOffloadConfig(local_cpu=True,
-                                                                  max_local_cpu_gb=a.reference_offload_gb)))
+                                                                  max_local_cpu_gb=a.reference_offload_gb)),
+                    open_loop=(dict(qps_per_gpu=a.open_loop_qps_per_gpu, seconds=a.open_loop_seconds,
+                                    users_per_gpu=a.reference_users_per_gpu, rounds=20, user_base=30_000_000)
+                               if a.open_loop_seconds > 0 else None))
             except Exception as e:  # the headline result stands on its own
                 ref = {"error": repr(e)} if rank == 0 else None
         if rank == 0:
@@ -434,7 +493,8 @@ async def rank_main(a: argparse.Namespace) -> None:
                         "p50_ttft_warm_rounds_s": ref["p50_ttft_warm_rounds_s"],
                         "p50_ttft_cold_round_s": ref["p50_ttft_cold_round_s"],
                         "round_times_s": ref["round_times_s"], "requests": ref["requests"],
-                        "failed_requests": ref["failed_requests"], "kv_tiers": ref["kv_tiers"],
+                        "failed_requests": ref["failed_requests"], "open_loop": ref["open_loop"],
+                        "kv_tiers": ref["kv_tiers"],
                         "per_replica": ref["per_replica"]}
             print(json.dumps(result), file=result_out, flush=True)
     finally:

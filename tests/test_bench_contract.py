@@ -5,6 +5,8 @@ and every replica served part of the load.  Tiny model, gloo."""
 
 import json
 import os
+
+import pytest
 import subprocess
 import sys
 
@@ -12,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--device", "cpu", "--model", "tiny-llama", "--users-per-gpu", "3", "--warmup-users-per-gpu", "1",
          "--sys-len", "40", "--history-len", "200", "--answer-len", "8", "--max-model-len", "2048",
          "--max-num-batched-tokens", "512", "--reference-users-per-gpu", "2",
-         "--reference-rounds", "2", "--reference-offload-gb", "0.05"]
+         "--reference-rounds", "2", "--reference-offload-gb", "0.05", "--open-loop-seconds", "4",
+         "--open-loop-qps-per-gpu", "2.0"]
 FIELDS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
           "vs_baseline", "dtype", "data", "config")
 
@@ -45,6 +48,10 @@ def test_two_ranks_under_torchrun():
     assert "error" not in ref, ref
     assert ref["failed_requests"] == 0 and ref["requests"] == 2 * 2 * 2 and ref["output_tok_per_s"] > 0
     assert ref["kv_tiers"]["host_stores_pages"] > 0
+    # ... and ends with one point of the reference's open-loop procedure
+    ol = ref["open_loop"]
+    assert "error" not in ol, ol
+    assert ol["requests"] > 0 and ol["mean_ttft_s"] > 0 and ol["offered_qps"] == pytest.approx(2 * 2.0)
     assert sum(r.get("host_loads_pages", 0) for r in ref["per_replica"]) > 0
     assert "Failed to scrape" not in p.stderr  # engines outlive the router at teardown
 

@@ -385,3 +385,26 @@ def test_transcription_proxy():
             async with s.http.post(s.url + "/v1/audio/transcriptions", data=form) as r:
                 assert r.status == 404
     run(go())
+
+
+def test_client_disconnect_mid_stream_is_handled_quietly(caplog):
+    """A client that hangs up while tokens are streaming: the router stops relaying, closes the
+    engine connection (so the engine can abort), logs one info line and no traceback, and keeps
+    serving."""
+    async def go():
+        async with Stack(1, engine_kw={}) as s:
+            s.engines[0].speed = 100  # 400 tokens = 4 s of stream
+            r = await s.http.post(s.url + "/v1/chat/completions", json={
+                "model": "fake", "messages": [{"role": "user", "content": "x"}], "max_tokens": 400, "stream": True})
+            await r.content.readany()
+            r.close()  # hang up with most of the stream still to come
+            await asyncio.sleep(0.6)
+            st, data, _ = await s.chat(max_tokens=3)
+            assert st == 200
+            assert any("disconnected before the end" in ln for ln in s.cap.lines), s.cap.lines
+            assert s.engines[0].aborted == 1  # the hang-up reached the engine
+
+    with caplog.at_level(logging.INFO):
+        run(go())
+    errors = [r.getMessage() for r in caplog.records if r.levelno >= logging.ERROR]
+    assert not errors, errors

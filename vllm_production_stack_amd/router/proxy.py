@@ -61,6 +61,7 @@ async def _relay(state, request: web.Request, method: str, url: str, headers: di
     mon.on_new_request(server_url, request_id, time.time())
     acc = bytearray() if want_body else None
     resp: web.StreamResponse | None = None
+    client_gone = False
     try:
         async with state.client.request(method, url, headers=headers, data=body,
                                         timeout=aiohttp.ClientTimeout(total=None)) as backend:
@@ -84,9 +85,20 @@ async def _relay(state, request: web.Request, method: str, url: str, headers: di
                     mon.on_request_chunk(server_url, request_id, now)
                 if acc is not None:
                     acc.extend(chunk)
-                await resp.write(chunk)
-            await resp.write_eof()
-        mon.on_request_complete(server_url, request_id, time.time())
+                try:
+                    await resp.write(chunk)
+                except ConnectionResetError:  # includes aiohttp's ClientConnectionResetError
+                    # the client went away mid-stream: stop relaying; leaving the ``async with``
+                    # closes the backend connection, which makes the engine abort the request
+                    client_gone = True
+                    break
+            if not client_gone:
+                await resp.write_eof()
+        if client_gone:
+            mon.on_request_failed(server_url, request_id, time.time())
+            logger.info("client of request %s disconnected before the end of the stream", request_id)
+        else:
+            mon.on_request_complete(server_url, request_id, time.time())
     except Exception:
         mon.on_request_failed(server_url, request_id, time.time())
         raise

@@ -91,6 +91,11 @@ class EngineStatsScraper:
                                    timeout=aiohttp.ClientTimeout(total=self.interval)) as r:
                 r.raise_for_status()
                 return EngineStats.from_vllm_scrape(await r.text())
+        except asyncio.TimeoutError:
+            # a busy engine answers late: its previous numbers stay in use, nothing failed
+            logger.warning("metrics scrape of %s took longer than %.0f s; keeping the previous sample", url,
+                           self.interval)
+            return self.engine_stats.get(url)
         except Exception as e:
             logger.error("Failed to scrape metrics from %s: %s", url, e)
             return None

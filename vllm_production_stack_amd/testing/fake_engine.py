@@ -28,6 +28,7 @@ class FakeEngine:
         self.api_key = api_key
         self.lora = list(lora or [])
         self.requests: list[dict] = []  # bodies seen, for assertions
+        self.aborted = 0  # streams whose peer hung up before the end
         self.headers_seen: list[dict] = []
         self.app = web.Application(client_max_size=64 * 1024 * 1024)
         r = self.app.router
@@ -114,7 +115,11 @@ class FakeEngine:
                 else:
                     d = {"id": "cmpl-" + rid, "object": "text_completion", "model": model,
                          "choices": [{"index": 0, "text": "Hello ", "finish_reason": None}]}
-                await resp.write(b"data: " + json.dumps(d).encode() + b"\n\n")
+                try:
+                    await resp.write(b"data: " + json.dumps(d).encode() + b"\n\n")
+                except ConnectionResetError:
+                    self.aborted += 1  # the peer hung up: a real engine aborts the request here
+                    return resp
             if (body.get("stream_options") or {}).get("include_usage"):
                 d = {"id": rid, "choices": [], "model": model,
                      "usage": {"prompt_tokens": 1, "completion_tokens": n, "total_tokens": n + 1}}
