@@ -273,15 +273,34 @@ async def run_phase(a, ctx, *, port0: int, routing: str, users_per_gpu: int, war
 
     loop = asyncio.get_running_loop()
     try:
-        cfg = EngineConfig(model=a.model, served_model_name=a.model, host="127.0.0.1",
-                           device="auto" if on_gpu else "cpu",
-                           dtype="auto" if on_gpu else "float32",
-                           port=port0 + 1 + rank, max_model_len=a.max_model_len, max_num_seqs=256,
-                           num_gpu_blocks_override=a.num_gpu_blocks or None, **engine_kwargs)
-        engine = LLMEngine(cfg)
-        ae = AsyncLLMEngine(engine)
-        ae.start(loop)
-        runner = await serve(ae, cfg.host, cfg.port)
+        # Bringing a replica up can fail on one rank only (host memory for the pinned tier, a port
+        # in use): the outcome is agreed on by all ranks before anyone waits at a barrier, so a
+        # failure ends the phase everywhere instead of hanging the ranks that succeeded.
+        start_error = None
+        try:
+            if os.environ.get("VPSA_BENCH_FAIL_START_RANK") == str(rank):  # test hook
+                raise MemoryError("injected start failure")
+            cfg = EngineConfig(model=a.model, served_model_name=a.model, host="127.0.0.1",
+                               device="auto" if on_gpu else "cpu",
+                               dtype="auto" if on_gpu else "float32",
+                               port=port0 + 1 + rank, max_model_len=a.max_model_len, max_num_seqs=256,
+                               num_gpu_blocks_override=a.num_gpu_blocks or None, **engine_kwargs)
+            engine = LLMEngine(cfg)
+            ae = AsyncLLMEngine(engine)
+            ae.start(loop)
+            runner = await serve(ae, cfg.host, cfg.port)
+        except Exception as e:  # noqa: BLE001
+            start_error = e
+        failed_ranks = [rank] if start_error is not None else []
+        if world > 1:
+            gathered = [None] * world
+            await loop.run_in_executor(None, lambda: dist.all_gather_object(
+                gathered, repr(start_error) if start_error is not None else None, group=gloo))
+            failed_ranks = [r for r, g in enumerate(gathered) if g is not None]
+            if failed_ranks and start_error is None:
+                start_error = RuntimeError(f"rank {failed_ranks[0]}: {gathered[failed_ranks[0]]}")
+        if failed_ranks:
+            raise RuntimeError(f"engine start failed on rank(s) {failed_ranks}: {start_error!r}")
         await loop.run_in_executor(None, barrier)  # every replica is listening
 
         if rank == 0:
@@ -391,6 +410,21 @@ async def run_phase(a, ctx, *, port0: int, routing: str, users_per_gpu: int, war
             ae.stop()
 
 
+def reference_offload_gb(a: argparse.Namespace, world: int) -> float:
+    """Pinned host memory per replica for the reference-configuration phase: what was asked for,
+    but never more than this machine can pin for all replicas at once (a third of what is
+    available, split evenly), and at least what one round of its users needs."""
+    want = float(a.reference_offload_gb)
+    try:
+        import psutil
+
+        avail_gb = psutil.virtual_memory().available / (1 << 30)
+        want = min(want, max(1.0, avail_gb / 3 / max(1, world)))
+    except Exception:  # noqa: BLE001
+        pass
+    return round(want, 2)
+
+
 def release_gpu_memory() -> None:
     """Between phases: the previous engine's weights, KV pool and graphs are unreachable once
     ``run_phase`` has returned; collect them and hand the blocks back to the driver."""
@@ -439,6 +473,7 @@ async def rank_main(a: argparse.Namespace) -> None:
         ref = None
         if a.reference_rounds > 0:
             release_gpu_memory()
+            offload_gb = reference_offload_gb(a, world)
             try:
                 ref = await run_phase(
                     a, ctx, port0=a.base_port + 20, routing="session", users_per_gpu=a.reference_users_per_gpu,
@@ -447,7 +482,7 @@ async def rank_main(a: argparse.Namespace) -> None:
                                        enable_prefix_caching=False, enable_chunked_prefill=False,
                                        prefill_step_ms=0.0,
                                        kv_offload=KVOffloadConfig(local_cpu=True,
-                                                                  max_local_cpu_gb=a.reference_offload_gb)),
+                                                                  max_local_cpu_gb=offload_gb)),
                     open_loop=(dict(qps_per_gpu=a.open_loop_qps_per_gpu, seconds=a.open_loop_seconds,
                                     users_per_gpu=a.reference_users_per_gpu, rounds=20, user_base=30_000_000)
                                if a.open_loop_seconds > 0 else None))
@@ -488,7 +523,7 @@ async def rank_main(a: argparse.Namespace) -> None:
                                 "off, KV offload to pinned host DRAM on, session routing on x-user-id "
                                 "(the reference's own benchmark setup)",
                         "users": a.reference_users_per_gpu * n, "rounds": a.reference_rounds,
-                        "cpu_offload_gb_per_replica": a.reference_offload_gb,
+                        "cpu_offload_gb_per_replica": offload_gb,
                         "output_tok_per_s": ref["tok_per_s"], "p50_ttft_s": ref["p50_ttft_s"],
                         "p50_ttft_warm_rounds_s": ref["p50_ttft_warm_rounds_s"],
                         "p50_ttft_cold_round_s": ref["p50_ttft_cold_round_s"],

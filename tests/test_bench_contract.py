@@ -65,3 +65,22 @@ def test_single_process_defaults_to_one_gpu():
     assert p.returncode == 0, p.stderr[-3000:]
     res = _one_json_line(p.stdout)
     assert res["n_gpus"] == 1 and res["config"]["global_batch"] == 3 and res["failed_requests"] == 0
+
+
+def test_a_replica_that_cannot_start_ends_the_run_on_every_rank():
+    """One rank fails while bringing its engine up (injected): the others must not wait for it at
+    a barrier.  The run ends quickly on all ranks, with the failing rank named."""
+    import time
+
+    env = dict(os.environ, OMP_NUM_THREADS="1", VPSA_BENCH_FAIL_START_RANK="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29741", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--base-port", "19900"] + SMALL
+    t0 = time.time()
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+    assert p.returncode != 0
+    assert time.time() - t0 < 120
+    assert "engine start failed on rank(s) [1]" in p.stderr, p.stderr[-2000:]
+    assert not p.stdout.strip()  # no half-measured JSON line
