@@ -140,6 +140,24 @@ def test_sleep_wake_cycle():
     run(_with_server(fn, enable_sleep_mode=True))
 
 
+def test_sleep_is_refused_while_requests_are_in_flight():
+    async def fn(s, eng):
+        body = {"model": "tiny-llama", "prompt": "a b c", "max_tokens": 200, "temperature": 0,
+                "ignore_eos": True, "stream": True}
+        async with s.post("/v1/completions", json=body) as r:
+            await r.content.readline()           # generation has started
+            async with s.post("/sleep?level=1") as z:
+                assert z.status == 409
+                assert "in flight" in (await z.json())["message"]
+            async with s.get("/is_sleeping") as z:
+                assert (await z.json())["is_sleeping"] is False
+            async for _ in r.content:             # the stream still finishes
+                pass
+        async with s.post("/sleep?level=1") as z:
+            assert z.status == 200
+    run(_with_server(fn, enable_sleep_mode=True))
+
+
 def test_embeddings_score_rerank():
     async def fn(s, eng):
         async with s.post("/v1/embeddings", json={"model": "tiny-llama", "input": ["a b", "c d e"]}) as r:

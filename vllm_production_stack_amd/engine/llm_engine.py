@@ -28,6 +28,10 @@ log = logging.getLogger("vpsa.engine")
 _TRACE = bool(os.environ.get("VPSA_TRACE_STEPS"))
 
 
+class EngineBusyError(RuntimeError):
+    """An operation that needs an idle engine was asked for while requests are in flight."""
+
+
 class LLMEngine:
     def __init__(self, cfg: EngineConfig, device: torch.device | None = None):
         self.cfg = cfg
@@ -220,7 +224,8 @@ class LLMEngine:
 
     # ------------------------------------------------------------------ sleep mode
     def sleep(self, level: int = 1) -> int:
-        assert not self.scheduler.running, "cannot sleep with requests in flight"
+        if self.scheduler.running or self.scheduler.waiting:
+            raise EngineBusyError("cannot sleep with requests in flight")
         self.bm.reset_prefix_cache()
         return self.runner.sleep(level)
 

@@ -10,6 +10,7 @@ probes of the reference consume from an engine process
 from __future__ import annotations
 
 import asyncio
+import hmac
 import json
 import logging
 import time
@@ -20,6 +21,7 @@ from aiohttp import web
 from .. import __version__
 from ..tracing import Tracer
 from .async_engine import AsyncLLMEngine
+from .llm_engine import EngineBusyError
 from .request import SamplingParams
 from .tokenizer import IncrementalDetokenizer
 from .tools import parse_tool_calls
@@ -131,7 +133,8 @@ class EngineServer:
     async def _auth(self, request: web.Request, handler):
         key = self.cfg.api_key
         if key and request.path not in _OPEN_PATHS:
-            if request.headers.get("Authorization", "") != f"Bearer {key}":
+            got = request.headers.get("Authorization", "").encode("utf-8", "replace")
+            if not hmac.compare_digest(got, f"Bearer {key}".encode()):
                 return web.json_response({"error": "Unauthorized"}, status=401)
         return await handler(request)
 
@@ -192,7 +195,10 @@ class EngineServer:
             return _err(400, "sleep mode is not enabled (--enable-sleep-mode)")
         level = int(request.query.get("level", "1"))
         t0 = time.time()
-        freed = await self.ae.call(lambda: self.engine.sleep(level))
+        try:
+            freed = await self.ae.call(lambda: self.engine.sleep(level))
+        except EngineBusyError as e:
+            return _err(409, str(e), "Conflict")
         log.info("Sleep mode freed %.2f GiB memory; it took %.6f seconds to fall asleep.",
                  freed / 2**30, time.time() - t0)
         return web.Response(status=200)
