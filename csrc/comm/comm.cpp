@@ -214,7 +214,11 @@ __device__ __forceinline__ uint32_t ar_pack(float a, float b) {
   return __builtin_bit_cast(uint32_t, v);
 }
 
-__global__ __launch_bounds__(AR_THREADS) void ar_oneshot_kernel(ArArgs a, uint16_t* data, long n) {
+// GATHER = false: in-place sum of `data` (n elements) over the ranks.
+// GATHER = true: `data` is this rank's n-element shard, `out` receives the shards of all ranks
+// in rank order (world * n elements); same publication, handshake and time-out.
+template <bool GATHER>
+__global__ __launch_bounds__(AR_THREADS) void ar_oneshot_kernel(ArArgs a, uint16_t* data, uint16_t* out, long n) {
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
   __shared__ uint32_t epoch_s;
   __shared__ int failed_s;
@@ -255,6 +259,15 @@ __global__ __launch_bounds__(AR_THREADS) void ar_oneshot_kernel(ArArgs a, uint16
       *a.err = 1;
       a.epochs[b] = e;
     }
+    return;
+  }
+  if (GATHER) {
+    for (int r = 0; r < a.world; ++r) {
+      const u4* from = reinterpret_cast<const u4*>(a.peers[r] + phase_off);
+      u4* to = reinterpret_cast<u4*>(out) + (long)r * groups;
+      for (long g = g0 + tid; g < g1; g += AR_THREADS) to[g] = __builtin_nontemporal_load(from + g);
+    }
+    if (tid == 0) a.epochs[b] = e;
     return;
   }
   u4* dst = reinterpret_cast<u4*>(data);
@@ -365,8 +378,27 @@ API int comm_ar_allreduce_bf16(void* ctx, void* data, long n, void* stream) {
   a.max_bytes = c->max_bytes;
   a.rank = c->rank;
   a.world = c->world;
-  hipLaunchKernelGGL(ar_oneshot_kernel, dim3(AR_BLOCKS), dim3(AR_THREADS), 0, (hipStream_t)stream, a,
-                     (uint16_t*)data, n);
+  hipLaunchKernelGGL(ar_oneshot_kernel<false>, dim3(AR_BLOCKS), dim3(AR_THREADS), 0, (hipStream_t)stream, a,
+                     (uint16_t*)data, (uint16_t*)nullptr, n);
+  return 0;
+}
+
+// All-gather of `n` bf16 elements per rank (a multiple of 8; both pointers 16-byte aligned):
+// out[r * n + i] = rank r's data[i].  Returns -1 when the shard does not fit.
+API int comm_ar_allgather_bf16(void* ctx, const void* data, void* out, long n, void* stream) {
+  bind_thread();
+  ArCtx* c = (ArCtx*)ctx;
+  if (n <= 0) return 0;
+  if ((n & 7) || (size_t)n * 2 > c->max_bytes || ((uintptr_t)data & 15) || ((uintptr_t)out & 15)) return -1;
+  ArArgs a;
+  for (int r = 0; r < AR_MAX_RANKS; ++r) a.peers[r] = c->peers[r];
+  a.epochs = c->epochs;
+  a.err = c->err;
+  a.max_bytes = c->max_bytes;
+  a.rank = c->rank;
+  a.world = c->world;
+  hipLaunchKernelGGL(ar_oneshot_kernel<true>, dim3(AR_BLOCKS), dim3(AR_THREADS), 0, (hipStream_t)stream, a,
+                     (uint16_t*)data, (uint16_t*)out, n);
   return 0;
 }
 

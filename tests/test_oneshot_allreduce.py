@@ -43,6 +43,18 @@ def _rank(rank, world, q_in, q_out, result):
         if not torch.equal(mine.cpu(), want):
             ok, detail = False, f"iteration {it}, n {n}: max diff {(mine.cpu().float() - want.float()).abs().max()}"
             break
+    # all-gather through the same buffers: every rank's shard in rank order
+    if ok:
+        for n in (8, 7 * 1024, 1 << 19):
+            shards = [torch.full((n,), float(r + 1), dtype=torch.bfloat16) + torch.arange(n).to(torch.bfloat16)
+                      for r in range(world)]
+            mine = shards[rank].to(dev)
+            assert ar.fits_gather(mine)
+            got = ar.all_gather(mine)
+            torch.cuda.synchronize()
+            if not torch.equal(got.cpu(), torch.stack(shards)):
+                ok, detail = False, f"all-gather of {n} elements differs"
+                break
     # replay from a HIP graph: the kernel advances its own epochs
     if ok:
         buf = torch.zeros(40 * 4096, dtype=torch.bfloat16, device=dev)

@@ -151,3 +151,52 @@ def test_a_timed_out_one_shot_all_reduce_fails_the_step_and_falls_back():
         state.check_collectives()  # and the next step runs (over RCCL)
     finally:
         tp.oneshot = old
+
+
+def test_decode_plan_travels_as_integers_and_back():
+    from vllm_production_stack_amd.engine.model_runner import ModelRunner as M
+
+    plan = {"bsz": 4, "ids": [11, 12, 13, 0], "pos": [5, 6, 700, 0], "slots": [69, 134, 7000, -1],
+            "ctx": [6, 7, 701, 0], "bt": [(0, 0, [1, 2, 3]), (2, 10, [109])]}
+    assert M._decode_plan_from_ints(M._decode_plan_to_ints(plan)) == plan
+    empty = {"bsz": 1, "ids": [3], "pos": [0], "slots": [64], "ctx": [1], "bt": []}
+    assert M._decode_plan_from_ints(M._decode_plan_to_ints(empty)) == empty
+
+
+def _ctrl_rank(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    from vllm_production_stack_amd.parallel import state
+    from vllm_production_stack_amd.parallel.launch import init_parallel_from_env
+
+    init_parallel_from_env(world, 1)
+    if state.get_replica().is_driver:
+        assert state.replica_broadcast_ints([7, -1, 1 << 40])
+        assert not state.replica_broadcast_ints(list(range(state.CTRL_WORDS)))  # too long: nothing is sent
+        state.replica_broadcast(("step", {"ids": [1, 2]}))
+        assert state.replica_broadcast_ints([])
+        state.replica_broadcast(("stop",))
+    else:
+        got = [state.replica_next() for _ in range(4)]
+        q.put(got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_control_channel_carries_integer_plans_inline_and_objects_pickled():
+    from vllm_production_stack_amd.parallel.state import CTRL_INTS, CTRL_OBJECT
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ctrl_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [(CTRL_INTS, [7, -1, 1 << 40]), (CTRL_OBJECT, ("step", {"ids": [1, 2]})),
+                   (CTRL_INTS, []), (CTRL_OBJECT, ("stop",))]

@@ -1,0 +1,109 @@
+"""Tensor-parallel replica with HIP-graph decode on every rank.
+
+Two processes share the one card of the test box (``VPSA_TP_BACKEND=gloo``: RCCL refuses two
+ranks on one device, so control messages and prefill-sized operands go over gloo through the
+host, and the decode-step collectives are the one-shot all-reduce / all-gather kernels over
+hipIpc-mapped buffers: the ones a captured graph contains).  The graph-replayed run must
+generate exactly what the eager run of the same layout generates, the worker rank must have
+captured and replayed its own graphs, and decode steps must travel as inline integer plans."""
+
+import copy
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from vllm_production_stack_amd.engine.config import EngineConfig
+from vllm_production_stack_amd.engine.request import SamplingParams
+
+pytestmark = pytest.mark.gpu
+
+SP = SamplingParams(max_tokens=12, temperature=0, ignore_eos=True)
+
+
+def _prompts():
+    g = torch.Generator().manual_seed(5)
+    return [torch.randint(16, 500, (n,), generator=g).tolist() for n in (150, 70, 9, 300)]
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, eager, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VPSA_TP_BACKEND="gloo",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    from vllm_production_stack_amd.engine.llm_engine import LLMEngine
+    from vllm_production_stack_amd.parallel.launch import init_parallel_from_env
+    from vllm_production_stack_amd.parallel.state import get_replica, get_tp
+
+    init_parallel_from_env(world, 1)
+    cfg = EngineConfig(model="tiny-llama-gqa", max_model_len=1024, max_num_seqs=8,
+                       max_num_batched_tokens=256, num_gpu_blocks_override=96, port=0,
+                       tensor_parallel_size=world, enforce_eager=eager)
+    eng = LLMEngine(cfg)
+    info = {"rank": rank, "graphs": len(eng.runner._graphs), "use_graphs": eng.runner.use_graphs,
+            "oneshot": get_tp().oneshot is not None}
+    if get_replica().is_driver:
+        outs = eng.generate(_prompts(), copy.deepcopy(SP))
+        outs2 = eng.generate(_prompts()[:2], copy.deepcopy(SP))  # through the prefix cache
+        info["failed"] = get_tp().oneshot.failed()
+        q.put(("driver", info, outs, outs2))
+        eng.shutdown()
+    else:
+        eng.runner.worker_loop()
+        info["failed"] = get_tp().oneshot.failed()
+        q.put(("worker", info, None, None))
+    dist.barrier()
+    get_tp().oneshot.close()
+    dist.destroy_process_group()
+
+
+def _run(eager: bool):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, eager, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue as _queue
+    import time as _time
+
+    got, deadline = [], _time.time() + 100
+    try:
+        while len(got) < world:
+            try:
+                got.append(q.get(timeout=1))
+            except _queue.Empty:
+                dead = [p for p in procs if p.exitcode not in (None, 0)]
+                if dead or _time.time() > deadline:
+                    raise AssertionError(f"rank failed or timed out (exit codes {[p.exitcode for p in procs]})")
+        for p in procs:
+            p.join(timeout=30)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    by = {g[0]: g for g in got}
+    return by["driver"], by["worker"]
+
+
+def test_tp2_graph_decode_matches_eager_and_runs_on_every_rank():
+    d_eager, w_eager = _run(eager=True)
+    d_graph, w_graph = _run(eager=False)
+    assert not d_eager[1]["use_graphs"] and d_eager[1]["oneshot"]
+    for info in (d_graph[1], w_graph[1]):
+        assert info["use_graphs"] and info["oneshot"] and info["graphs"] > 0, info
+        assert not info["failed"], info
+    assert d_graph[2] == d_eager[2], (d_graph[2], d_eager[2])
+    assert d_graph[3] == d_eager[3]
+    assert all(len(o) == SP.max_tokens for o in d_graph[2])

@@ -26,8 +26,9 @@ import torch
 from .. import ops
 from ..models.batch import BatchMeta
 from ..models.loader import build_model
-from ..parallel.state import (check_collectives, get_pp, get_replica, get_tp, pp_recv, pp_send, replica_broadcast,
-                              replica_min_int)
+from ..parallel.state import (CTRL_INTS, check_collectives, enable_oneshot_all_reduce, get_pp, get_replica, get_tp,
+                              pp_recv, pp_send, replica_broadcast, replica_broadcast_ints, replica_min_int,
+                              replica_next)
 from .block_manager import PAGE
 from .config import EngineConfig, ModelConfig
 from .sampler import Sampler
@@ -69,17 +70,38 @@ class ModelRunner:
             (self.num_pages, self.n_layers_local, 2, self.n_kv_local, PAGE * self.kv_head_dim),
             dtype=self.dtype, device=device)
         self.sampler = Sampler(device, cfg.seed)
-        # collectives and stage hand-offs run eagerly: graphs only for single-process replicas
         # graphs need the HIP attention kernels (the generic path reads lengths on the host)
-        self.use_graphs = (device.type == "cuda" and not cfg.enforce_eager and not self.distributed
-                           and self.kv_head_dim == ops.HEAD_DIM_HIP)
+        self.use_graphs = (device.type == "cuda" and not cfg.enforce_eager
+                           and self.kv_head_dim == ops.HEAD_DIM_HIP
+                           and (not self.distributed or self._tp_graphs_ready()))
         self._graphs: dict[int, dict] = {}
+        self._row_track: dict[tuple, dict] = {}  # driver: what each graph row's block table holds
         self._graph_pool = None
         self._pin = device.type == "cuda"
         self.sleeping = False
         self._sleep_stash: list[tuple[torch.Tensor, torch.Tensor]] = []
         # host-side seconds of eager steps: plan lists, device tensors, kernel launches
         self.t_plan = self.t_materialize = self.t_launch = 0.0
+
+    def _tp_graphs_ready(self) -> bool:
+        """Tensor-parallel replicas (no pipeline stages) replay decode graphs on every rank when
+        the collectives inside them are graph-replayable kernels of this package: the one-shot
+        all-reduce and all-gather over mapped peer buffers.  The buffers are re-created here when
+        the logits shard of the largest graph batch would not fit.  ``VPSA_TP_GRAPHS=rccl``
+        captures the RCCL collectives instead (not measured on hardware); pipeline stages and
+        everything else run eagerly."""
+        import os
+
+        tp, pp = get_tp(), get_pp()
+        if pp.size > 1 or tp.size == 1 or self.dtype != torch.bfloat16:
+            return False
+        if tp.oneshot is None:
+            return os.environ.get("VPSA_TP_GRAPHS", "") == "rccl"
+        top = self._bucket(min(self.cfg.max_num_seqs, _GRAPH_BUCKETS[-1]))
+        need = top * max(self.model.lm_head.shape[0], self.model_cfg.hidden_size) * 2
+        if need > tp.oneshot.max_elems * 2:
+            enable_oneshot_all_reduce(self.device, max_bytes=(need + (1 << 20) - 1) >> 20 << 20)
+        return True
 
     # ------------------------------------------------------------------ memory plan
     def _plan_pages(self) -> int:
@@ -272,20 +294,31 @@ class ModelRunner:
         assert self.distributed and not self.replica.is_driver
         with torch.inference_mode():
             while True:
-                msg = replica_broadcast(None)
+                ctrl, msg = replica_next()
+                if ctrl == CTRL_INTS:  # a decode step that replays this rank's captured graph
+                    self._replay_decode(self._decode_plan_from_ints(msg))
+                    self._check_worker_collectives()
+                    continue
                 kind = msg[0]
                 if kind == "stop":
                     return
                 if kind == "step":
                     self._run_plan(msg[1])
-                    try:
-                        check_collectives()  # lags a step on worker ranks (they never read back)
-                    except RuntimeError as e:
-                        log.error("%s", e)
+                    self._check_worker_collectives()
+                elif kind == "dstep":
+                    self._replay_decode(msg[1])
+                    self._check_worker_collectives()
                 elif kind == "sleep":
                     self._sleep_local(msg[1])
                 elif kind == "wake":
                     self._wake_local()
+
+    @staticmethod
+    def _check_worker_collectives() -> None:
+        try:
+            check_collectives()  # lags a step on worker ranks (they never read back)
+        except RuntimeError as e:
+            log.error("%s", e)
 
     def stop_workers(self) -> None:
         if self.distributed and self.replica.is_driver:
@@ -302,6 +335,7 @@ class ModelRunner:
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         self._graphs.clear()
+        self._row_track.clear()
         self._graph_pool = None
         self._sleep_stash = []
         # shrink the storages themselves: the transfer receiver, the tier connector and the
@@ -351,7 +385,6 @@ class ModelRunner:
             "bt": torch.zeros((bsz, mp), dtype=torch.int32, device=dev),
             "h64": h64, "h32": h32, "hbt": hbt,
             "n64": h64.numpy(), "n32": h32.numpy(), "nbt": hbt.numpy(),
-            "row_pages": [None] * bsz, "row_len": [0] * bsz,
         }
         splits = ops.decode_num_splits(bsz, self.n_kv_local, self.max_model_len)
         mc = self.model_cfg
@@ -384,10 +417,81 @@ class ModelRunner:
         return st
 
     def _execute_decode_graph(self, decodes: list[ScheduledSeq]):
+        """Driver: describe the step as a compact plan (per-row scalars and the block-table rows
+        that changed), send it to the replica's other ranks, replay the graph, sample."""
         n = len(decodes)
         bsz = self._bucket(n)
         lora = self.model.lora
         with_lora = lora is not None and any(s.req.lora_slot >= 0 for s in decodes)
+        ids, pos, slots, ctx = [0] * bsz, [0] * bsz, [-1] * bsz, [0] * bsz
+        # which request's page list each graph row held last step, and how much of it: a row of
+        # the block table is resent only when another request moves in or its list has grown
+        key = (bsz, True) if with_lora else bsz
+        st = self._graphs.get(key)
+        if st is None or (with_lora and st["lora_version"] != lora.version):
+            self._row_track.pop(key, None)  # the graph about to be captured starts from an empty table
+        track = self._row_track.setdefault(key, {"pages": [None] * bsz, "len": [0] * bsz})
+        row_pages, row_len = track["pages"], track["len"]
+        bt: list[tuple[int, int, list[int]]] = []
+        for i, s in enumerate(decodes):
+            r = s.req
+            t = s.start
+            pages = r.pages
+            ids[i] = r.output_ids[t - r.prompt_len] if t >= r.prompt_len else r.prompt_ids[t]
+            pos[i] = t
+            slots[i] = pages[t // PAGE] * PAGE + t % PAGE
+            ctx[i] = t + 1
+            k = len(pages)
+            if row_pages[i] is not pages:  # another request (or a re-admitted one) moved in
+                bt.append((i, 0, pages[:k]))
+                row_pages[i], row_len[i] = pages, k
+            elif row_len[i] != k:  # page lists only grow while a request keeps its list
+                lo = min(row_len[i], k)
+                bt.append((i, lo, pages[lo:k]))
+                row_len[i] = k
+        for i in range(n, bsz):  # rows past the batch hold no request (ctx 0: nothing is read)
+            row_pages[i] = None
+        plan = {"bsz": bsz, "ids": ids, "pos": pos, "slots": slots, "ctx": ctx, "bt": bt}
+        if with_lora:
+            plan["lora"] = [s.req.lora_slot for s in decodes] + [-1] * (bsz - n)
+        if self.distributed:
+            if not replica_broadcast_ints(self._decode_plan_to_ints(plan)):
+                replica_broadcast(("dstep", plan))
+        st = self._replay_decode(plan)
+        reqs = [s.req for s in decodes]
+        toks, infos = self.sampler.sample(st["logits"], reqs, st["toks"])
+        if self.distributed:
+            check_collectives()
+        return list(zip(decodes, toks, infos))
+
+    @staticmethod
+    def _decode_plan_to_ints(plan: dict) -> list[int]:
+        """[bsz, n_deltas, ids.., pos.., slots.., ctx.., (row, lo, count, pages..)..]"""
+        out = [plan["bsz"], len(plan["bt"])]
+        out += plan["ids"] + plan["pos"] + plan["slots"] + plan["ctx"]
+        for row, lo, pages in plan["bt"]:
+            out += [row, lo, len(pages)]
+            out += pages
+        return out
+
+    @staticmethod
+    def _decode_plan_from_ints(v: list[int]) -> dict:
+        bsz, nd = v[0], v[1]
+        cut = [2 + k * bsz for k in range(5)]
+        plan = {"bsz": bsz, "ids": v[cut[0]:cut[1]], "pos": v[cut[1]:cut[2]],
+                "slots": v[cut[2]:cut[3]], "ctx": v[cut[3]:cut[4]], "bt": []}
+        p = cut[4]
+        for _ in range(nd):
+            row, lo, cnt = v[p:p + 3]
+            plan["bt"].append((row, lo, v[p + 3:p + 3 + cnt]))
+            p += 3 + cnt
+        return plan
+
+    def _replay_decode(self, plan: dict) -> dict:
+        """Every rank of the replica: write the plan into this rank's graph inputs and replay."""
+        bsz = plan["bsz"]
+        with_lora = "lora" in plan
+        lora = self.model.lora
         # graphs with adapter kernels are keyed apart and follow the adapter set: which
         # (projection, layer) pairs launch LoRA kernels is decided on the host at capture time
         key = (bsz, True) if with_lora else bsz
@@ -400,42 +504,19 @@ class ModelRunner:
             self._graphs[key] = st
             log.info("captured decode graph for batch %d%s in %.2fs", bsz,
                      " (LoRA)" if with_lora else "", time.time() - t0)
-        ids, pos, slots, ctx = [0] * bsz, [0] * bsz, [-1] * bsz, [0] * bsz
-        nbt, row_pages, row_len = st["nbt"], st["row_pages"], st["row_len"]
-        bt_dirty = False
-        for i, s in enumerate(decodes):
-            r = s.req
-            t = s.start
-            pages = r.pages
-            ids[i] = r.output_ids[t - r.prompt_len] if t >= r.prompt_len else r.prompt_ids[t]
-            pos[i] = t
-            slots[i] = pages[t // PAGE] * PAGE + t % PAGE
-            ctx[i] = t + 1
-            k = len(pages)
-            if row_pages[i] is not pages:  # another request (or a re-admitted one) moved in
-                nbt[i, :k] = pages
-                row_pages[i], row_len[i] = pages, k
-                bt_dirty = True
-            elif row_len[i] != k:  # page lists only grow while a request keeps its list
-                lo = min(row_len[i], k)
-                nbt[i, lo:k] = pages[lo:k]
-                row_len[i] = k
-                bt_dirty = True
-        for i in range(n, bsz):  # rows past the batch hold no request (ctx 0: nothing is read)
-            row_pages[i] = None
+        nbt = st["nbt"]
+        for row, lo, pages in plan["bt"]:
+            nbt[row, lo:lo + len(pages)] = pages
         n64, n32 = st["n64"], st["n32"]
-        n64[0], n64[1], n32[0], n32[1] = ids, slots, pos, ctx
+        n64[0], n64[1], n32[0], n32[1] = plan["ids"], plan["slots"], plan["pos"], plan["ctx"]
         st["d64"].copy_(st["h64"], non_blocking=True)
         st["d32"].copy_(st["h32"], non_blocking=True)
-        if bt_dirty:
+        if plan["bt"]:
             st["bt"].copy_(st["hbt"], non_blocking=True)
         if with_lora:
-            ls = [s.req.lora_slot for s in decodes] + [-1] * (bsz - n)
-            st["lora"].copy_(self._to_dev(ls, torch.int32), non_blocking=True)
+            st["lora"].copy_(self._to_dev(plan["lora"], torch.int32), non_blocking=True)
         st["graph"].replay()
-        reqs = [s.req for s in decodes]
-        toks, infos = self.sampler.sample(st["logits"], reqs, st["toks"])
-        return list(zip(decodes, toks, infos))
+        return st
 
     def capture_all_graphs(self) -> int:
         """Capture the decode graph of every batch bucket up to ``max_num_seqs`` (largest first:
@@ -461,6 +542,7 @@ class ModelRunner:
     def _sleep_local(self, level: int = 1) -> int:
         freed = 0
         self._graphs.clear()
+        self._row_track.clear()
         self._graph_pool = None
         if self.device.type == "cuda":
             for t in self.model.weight_tensors():

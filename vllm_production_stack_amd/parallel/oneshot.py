@@ -36,6 +36,8 @@ def _comm():
         lib.comm_ar_max_elems.argtypes = [c_void_p]
         lib.comm_ar_allreduce_bf16.restype = c_int
         lib.comm_ar_allreduce_bf16.argtypes = [c_void_p, c_void_p, c_long, c_void_p]
+        lib.comm_ar_allgather_bf16.restype = c_int
+        lib.comm_ar_allgather_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_long, c_void_p]
         lib.comm_ar_failed.restype = c_int
         lib.comm_ar_failed.argtypes = [c_void_p]
         lib.comm_ar_failed_nosync.argtypes = [c_void_p]
@@ -49,7 +51,8 @@ class OneShotAllReduce:
     """``exchange(my_handle: bytes) -> list[bytes]`` must return every rank's handle in rank
     order (e.g. ``dist.all_gather_object`` over the group's gloo side channel)."""
 
-    def __init__(self, rank: int, world: int, device: torch.device, exchange, max_bytes: int = 4 << 20):
+    def __init__(self, rank: int, world: int, device: torch.device, exchange, max_bytes: int = 4 << 20,
+                 reduce_max_bytes: int | None = None):
         lib = _comm()
         self.lib, self.rank, self.world, self.device = lib, rank, world, device
         lib.comm_bind_device(device.index if device.index is not None else torch.cuda.current_device())
@@ -68,10 +71,19 @@ class OneShotAllReduce:
         if rc != 0:
             raise RuntimeError(f"one-shot all-reduce: could not map the buffer of rank {-rc - 1}")
         self.max_elems = int(lib.comm_ar_max_elems(self.ctx))
+        # sums above this size go to RCCL (32 workgroups are sized for decode-step operands); a
+        # gather may use the whole buffer (every rank has to read every shard whatever the route)
+        self.reduce_max_elems = min(self.max_elems, (reduce_max_bytes or max_bytes) // 2)
+
+    def _ok(self, x: torch.Tensor, limit: int) -> bool:
+        return (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.numel() % 8 == 0
+                and 0 < x.numel() <= limit and x.data_ptr() % 16 == 0)
 
     def fits(self, x: torch.Tensor) -> bool:
-        return (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.numel() % 8 == 0
-                and 0 < x.numel() <= self.max_elems and x.data_ptr() % 16 == 0)
+        return self._ok(x, self.reduce_max_elems)
+
+    def fits_gather(self, x: torch.Tensor) -> bool:
+        return self._ok(x, self.max_elems)
 
     def all_reduce(self, x: torch.Tensor) -> torch.Tensor:
         """In-place sum over the ranks on the current stream."""
@@ -80,6 +92,17 @@ class OneShotAllReduce:
         if rc != 0:
             raise RuntimeError("one-shot all-reduce: operand does not fit")
         return x
+
+    def all_gather(self, x: torch.Tensor) -> torch.Tensor:
+        """[world, *x.shape]: every rank's ``x`` in rank order, on the current stream (same
+        publication and handshake as the sum; graph-replayable)."""
+        out = torch.empty((self.world, *x.shape), dtype=x.dtype, device=x.device)
+        rc = self.lib.comm_ar_allgather_bf16(self.ctx, c_void_p(x.data_ptr()), c_void_p(out.data_ptr()),
+                                             c_long(x.numel()),
+                                             c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("one-shot all-gather: operand does not fit")
+        return out
 
     def failed(self) -> bool:
         """True if a call gave up waiting for a peer (synchronises the device)."""

@@ -31,6 +31,7 @@ class TPGroup:
     group: "dist.ProcessGroup | None" = None
     cpu_group: "dist.ProcessGroup | None" = None  # gloo side channel for control messages
     oneshot: object = None  # OneShotAllReduce when enabled (small bf16 all-reduces)
+    host_staged: "bool | None" = None  # GPU operands over a gloo group (one-card rehearsal)
 
     @property
     def is_driver(self) -> bool:
@@ -149,20 +150,29 @@ def init_replica_parallel(tp_size: int, pp_size: int = 1) -> None:
                                first=base + t, last=base + (pp_size - 1) * tp_size + t))
 
 
-def enable_oneshot_all_reduce(device: torch.device, max_bytes: int = 4 << 20) -> bool:
+def enable_oneshot_all_reduce(device: torch.device, max_bytes: int = 4 << 20,
+                              reduce_max_bytes: int = 4 << 20) -> bool:
     """Map the tensor-parallel peers' published buffers (hipIpc) so that small bf16 all-reduces
-    take the one-shot kernel of ``parallel/oneshot.py``.  All ranks of the group call this."""
+    and all-gathers take the one-shot kernels of ``parallel/oneshot.py``.  All ranks of the group
+    call this; calling it again replaces the buffers (e.g. by larger ones)."""
     tp = _TP
     if tp.size == 1 or device.type != "cuda":
         return False
     from .oneshot import OneShotAllReduce
+
+    if tp.oneshot is not None:
+        torch.cuda.synchronize(device)
+        dist.barrier(group=tp.cpu_group)  # nobody unmaps while a peer's kernel still reads
+        tp.oneshot.close()
+        tp.oneshot = None
+        dist.barrier(group=tp.cpu_group)
 
     def exchange(handle: bytes) -> list[bytes]:
         got: list = [None] * tp.size
         dist.all_gather_object(got, handle, group=tp.cpu_group)
         return got
 
-    tp.oneshot = OneShotAllReduce(tp.rank, tp.size, device, exchange, max_bytes)
+    tp.oneshot = OneShotAllReduce(tp.rank, tp.size, device, exchange, max_bytes, reduce_max_bytes)
     return True
 
 
@@ -182,12 +192,25 @@ def check_collectives() -> None:
                            "one-shot all-reduce disabled, falling back to RCCL")
 
 
+def _host_staged(tp: TPGroup) -> bool:
+    """GPU tensors over a gloo group (several ranks rehearsing on ONE card, where RCCL refuses to
+    form a communicator): operands that the one-shot kernels do not take go through the host."""
+    if tp.host_staged is None:
+        tp.host_staged = dist.get_backend(tp.group) == "gloo"
+    return tp.host_staged
+
+
 def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
     tp = _TP
     if tp.size == 1:
         return x
     if tp.oneshot is not None and tp.oneshot.fits(x):
         return tp.oneshot.all_reduce(x)
+    if x.is_cuda and _host_staged(tp):
+        h = x.float().cpu()  # summed in fp32, like the one-shot kernel
+        dist.all_reduce(h, group=tp.group)
+        x.copy_(h)
+        return x
     nbytes = x.numel() * x.element_size()
     if nbytes >= TWO_SHOT_BYTES and x.shape[0] % tp.size == 0 and x.is_contiguous():
         shard = torch.empty((x.shape[0] // tp.size, *x.shape[1:]), dtype=x.dtype, device=x.device)
@@ -205,6 +228,13 @@ def tp_all_gather_last_dim(x: torch.Tensor) -> torch.Tensor:
         return x
     x = x.contiguous().view(-1, x.shape[-1])
     lead = x.shape[0]
+    if tp.oneshot is not None and tp.oneshot.fits_gather(x):
+        out = tp.oneshot.all_gather(x)  # [tp, lead, n]
+        return out.movedim(0, 1).reshape(lead, tp.size * x.shape[1])
+    if x.is_cuda and _host_staged(tp):
+        parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(tp.size)]
+        dist.all_gather(parts, x.cpu(), group=tp.group)
+        return torch.cat(parts, dim=1).to(x.device)
     out = torch.empty((tp.size * lead, x.shape[1]), dtype=x.dtype, device=x.device)
     dist.all_gather_into_tensor(out, x, group=tp.group)  # rank-major concatenation along dim 0
     return out.view(tp.size, lead, x.shape[1]).movedim(0, 1).reshape(lead, tp.size * x.shape[1])
@@ -220,14 +250,58 @@ def pp_recv(shape, dtype: torch.dtype, device: torch.device, src: int) -> torch.
     return t
 
 
+# Control channel of a replica (driver -> every rank, gloo).  Every message starts with ONE
+# fixed-size int64 tensor: word 0 is the kind, word 1 the payload length.  A decode step that
+# replays a captured graph travels entirely inside that tensor (token ids, positions, slots,
+# context lengths and the block-table rows that changed: a few hundred integers), so the common
+# step costs one small broadcast and no pickling; everything else announces a pickled object that
+# follows in a second broadcast.
+CTRL_WORDS = 4096
+CTRL_OBJECT, CTRL_INTS = 1, 2
+
+
+def _ctrl_tensor(kind: int, payload=()) -> torch.Tensor:
+    t = torch.zeros(CTRL_WORDS, dtype=torch.int64)
+    t[0], t[1] = kind, len(payload)
+    if len(payload):
+        t[2:2 + len(payload)] = torch.as_tensor(payload, dtype=torch.int64)
+    return t
+
+
 def replica_broadcast(obj):
-    """Broadcast a picklable control message from the replica's driver to all its ranks."""
+    """Driver: send a picklable control message to all ranks of the replica."""
     r = _REPLICA
     if r.size == 1:
         return obj
+    dist.broadcast(_ctrl_tensor(CTRL_OBJECT), src=r.driver, group=r.cpu_group)
     box = [obj]
     dist.broadcast_object_list(box, src=r.driver, group=r.cpu_group)
     return box[0]
+
+
+def replica_broadcast_ints(payload) -> bool:
+    """Driver: send a list of integers inside the header tensor itself.  False when it does not
+    fit (the caller then sends it as an object)."""
+    r = _REPLICA
+    if r.size == 1:
+        return True
+    if len(payload) > CTRL_WORDS - 2:
+        return False
+    dist.broadcast(_ctrl_tensor(CTRL_INTS, payload), src=r.driver, group=r.cpu_group)
+    return True
+
+
+def replica_next():
+    """Worker ranks: the driver's next message, ``(CTRL_OBJECT, obj)`` or ``(CTRL_INTS, list)``."""
+    r = _REPLICA
+    t = torch.zeros(CTRL_WORDS, dtype=torch.int64)
+    dist.broadcast(t, src=r.driver, group=r.cpu_group)
+    kind, n = int(t[0]), int(t[1])
+    if kind == CTRL_INTS:
+        return kind, t[2:2 + n].tolist()
+    box = [None]
+    dist.broadcast_object_list(box, src=r.driver, group=r.cpu_group)
+    return CTRL_OBJECT, box[0]
 
 
 def replica_min_int(v: int) -> int:
