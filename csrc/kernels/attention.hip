@@ -994,12 +994,507 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v3(
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Fourth-generation prefill kernel: the data path of the third generation (64 query rows per
+// wave, one wave per SIMD with the whole register file, O accumulators in AGPRs, ring of three
+// 32 KiB tile buffers, lazy rescale) with the instruction stream re-timed so that every MFMA gap
+// carries ONE exponential:
+//   * a step still issues 32 MFMAs for one 32-key half tile u, but in the order
+//       gaps  0- 7: O += V^T(keys 16-31 of u-1) . P      (probabilities packed in the step before)
+//       gaps  8-23: scores of half tile u+1
+//       gaps 24-31: O += V^T(keys  0-15 of u)   . P
+//     so the 32 exponentials of u have the whole step: one per gap (the third generation needed
+//     24 of them under the first 16 MFMAs), each with its fma issued at least one gap earlier
+//     and its add / pack one gap later: no instruction waits for the one before it;
+//   * the fmas of the last eight values are issued early (gaps 8-15), which leaves gaps 25-31 to
+//     the row maxima of the new scores; staging (8 global loads in the first step of a tile,
+//     8 LDS writes in the second) sits in gaps 16-23;
+//   * the barrier of a tile is between its two steps: the buffer that receives tile t+2 is last
+//     read (V of tile t-1, keys 48-63) at the start of the first step of tile t;
+//   * a rescale (rare) also scales the packed probabilities that are still waiting for their
+//     MFMAs; row maxima use v_max3 written as asm (the compiler otherwise canonicalises MFMA
+//     results with an extra v_max before every fmaxf); PV MFMAs carry no wait states (their
+//     operands were written several instructions earlier).
+// grid = (num_tiles of 64 rows, n_kv * G / 4); block = 256; dynamic LDS = 96 KiB.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void mfma_acc_agpr_now(f32x16& acc, bf16x8 a, bf16x8 b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float d;
+  asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+template <bool HEAD_MAJOR>
+__global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
+    const uint16_t* __restrict__ q, long q_stride, uint16_t* __restrict__ out, long out_stride,
+    const uint16_t* __restrict__ cache, long page_stride, long v_offset,
+    const int* __restrict__ block_tables, int max_blocks, const int* __restrict__ cu_q,
+    const int* __restrict__ ctx_lens, const int* __restrict__ tile_seq,
+    const int* __restrict__ tile_q0, int n_q, int n_kv, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // 3 x (16 KiB K + 16 KiB V)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31;
+  const int h = lane >> 5;
+
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (HEAD_MAJOR) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    by = lin % gridDim.y;
+    bx = lin / gridDim.y;
+  }
+  const int G = n_q / n_kv;
+  const int groups_per_kv = G >> 2;
+  const int kvh = by / groups_per_kv;
+  const int head = kvh * G + (by % groups_per_kv) * 4 + wave;
+
+  const int seq = tile_seq[bx];
+  const int q0 = tile_q0[bx];
+  const int row0 = cu_q[seq];
+  const int q_len = cu_q[seq + 1] - row0;
+  const int ctx = ctx_lens[seq];
+  const int pos0 = ctx - q_len;
+
+  int my_row[2], my_pos[2];
+  bool row_ok[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    my_row[rb] = q0 + 32 * rb + r;
+    row_ok[rb] = my_row[rb] < q_len;
+    my_pos[rb] = row_ok[rb] ? pos0 + my_row[rb] : ctx - 1;
+  }
+  int b_last = q0 + 63;
+  if (b_last > q_len - 1) b_last = q_len - 1;
+  const int n_tiles = (pos0 + b_last) / PAGE + 1;
+  const int last = n_tiles - 1;
+  // tiles [0, n_full) lie entirely at or below the first row's position: no mask for any row
+  const int n_full = (pos0 + q0 + 1) / PAGE;
+
+  bf16x8 qf[2][8];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const uint16_t* qp =
+        q + (long)(row0 + (row_ok[rb] ? my_row[rb] : 0)) * q_stride + head * HEAD_DIM + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + 16 * ks);
+      if (!row_ok[rb]) v = (u32x4){0, 0, 0, 0};
+      qf[rb][ks] = __builtin_bit_cast(bf16x8, v);
+      asm volatile("" : "+a"(qf[rb][ks]));  // an AGPR value from here on
+    }
+  }
+
+  const int* bt = block_tables + (long)seq * max_blocks;
+  const long kv_head_off = (long)kvh * PAGE * HEAD_DIM;
+
+  u32x4 sk[4], sv[4];
+  auto stage_load = [&](int tile) {
+    const long page = bt[tile];
+    const uint16_t* kp = cache + page * page_stride + kv_head_off + tid * 8;
+    const uint16_t* vp = kp + v_offset;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sk[i] = *reinterpret_cast<const u32x4*>(kp + i * 2048);
+      sv[i] = *reinterpret_cast<const u32x4*>(vp + i * 2048);
+    }
+  };
+  int wk_off[4], wv_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = i * 256 + tid;
+    const int key = id >> 4, c = id & 15;
+    wk_off[i] = key * 256 + ((c ^ (key & 15)) << 4);
+    const int d = id >> 3, cv = id & 7;
+    wv_off[i] = 16384 + d * 128 + ((cv ^ ((d >> 1) & 7)) << 4);
+  }
+  auto stage_write = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4*>(buf + wk_off[i]) = sk[i];
+      *reinterpret_cast<u32x4*>(buf + wv_off[i]) = sv[i];
+    }
+  };
+
+  f32x16 o_acc[2][4];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o_acc[rb][dt][i] = 0.f;
+  float m_run[2] = {NEG_BIG, NEG_BIG};
+  float l_run[2] = {0.f, 0.f};
+
+  const int krow = (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1);
+  const int k_sw = krow & 15;
+  const int k_row_off = krow * 256;
+  int v_row_off[4], v_sw[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const int d = 32 * dt + r;
+    v_row_off[dt] = 16384 + d * 128;
+    v_sw[dt] = (d >> 1) & 7;
+  }
+  auto k_frag = [&](const char* buf, int tt, int ks) {
+    return lds_read_frag(buf, tt * 8192 + k_row_off + (((2 * ks + h) ^ k_sw) << 4));
+  };
+  auto v_frag = [&](const char* buf, int tt, int sh, int dt) {
+    return lds_read_frag(buf, v_row_off[dt] + (((4 * tt + 2 * sh + h) ^ v_sw[dt]) << 4));
+  };
+
+  // ---- plain (compiler-scheduled) pieces: prologue, last tile
+  auto qk_half = [&](const char* buf, int tt, f32x16 (&s)[2]) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      s[0][i] = 0.f;
+      s[1][i] = 0.f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      bf16x8 a = k_frag(buf, tt, ks);
+      s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0][ks], s[0], 0, 0, 0);
+      s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[1][ks], s[1], 0, 0, 0);
+    }
+  };
+  // accumulator reg i of lane half h = key kbase + 32 tt + 16 (i>>3) + 8 h + (i&7)
+  auto mask_half = [&](int tile, int tt, f32x16 (&s)[2]) {
+    const int kb = tile * PAGE + 32 * tt + 8 * h;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (kb + 16 * (i >> 3) + (i & 7) > my_pos[rb]) s[rb][i] = NEG_BIG;
+  };
+  auto max_half = [&](const f32x16 (&s)[2], float (&mt)[2]) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      float mx0 = fmaxf(s[rb][0], s[rb][1]);
+      float mx1 = fmaxf(s[rb][2], s[rb][3]);
+#pragma unroll
+      for (int i = 4; i < 16; i += 4) {
+        mx0 = fmaxf(fmaxf(mx0, s[rb][i]), s[rb][i + 1]);
+        mx1 = fmaxf(fmaxf(mx1, s[rb][i + 2]), s[rb][i + 3]);
+      }
+      float mx = fmaxf(mx0, mx1);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mt[rb] = fmaxf(mx * scale_log2e, NEG_BIG);
+    }
+  };
+  // packed probabilities of the 16-key slice still waiting for its MFMAs (keys 16-31 of the
+  // half tile exponentiated last); zero before the first step
+  u32x4 pw1[2] = {(u32x4){0, 0, 0, 0}, (u32x4){0, 0, 0, 0}};
+  auto rescale = [&](const float (&mt)[2]) {
+    const bool grow = (mt[0] > m_run[0] + LAZY_THR) || (mt[1] > m_run[1] + LAZY_THR);
+    if (__any(grow)) {
+      mfma_drain();
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const float m_new = fmaxf(m_run[rb], mt[rb]);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_new);
+        m_run[rb] = m_new;
+        l_run[rb] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o_acc[rb][dt][i] *= alpha;
+        // the waiting probabilities were taken against the old maximum
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          pw1[rb][j] = pack_bf16x2(bf16lo(pw1[rb][j]) * alpha, bf16hi(pw1[rb][j]) * alpha);
+      }
+      asm volatile("s_nop 1" ::: "memory");
+    }
+  };
+  // probabilities of 16-key slice `sh` of the scores `s`, packed; adds their sums to l_run
+  auto exp_slice = [&](const f32x16 (&s)[2], int sh, u32x4 (&pk)[2]) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const float nm = -m_run[rb];
+      float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[rb][8 * sh + 2 * jj], scale_log2e, nm));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[rb][8 * sh + 2 * jj + 1], scale_log2e, nm));
+        ps0 += p0;
+        ps1 += p1;
+        pk[rb][jj] = pack_bf16x2(p0, p1);
+      }
+      l_run[rb] += ps0 + ps1;
+    }
+  };
+  // O^T += V^T(16-key slice sh of half tt) . P^T
+  auto pv_slice = [&](const char* buf, int tt, int sh, const u32x4 (&pk)[2]) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      bf16x8 a = v_frag(buf, tt, sh, dt);
+      mfma_acc_agpr(o_acc[0][dt], a, __builtin_bit_cast(bf16x8, pk[0]));
+      mfma_acc_agpr(o_acc[1][dt], a, __builtin_bit_cast(bf16x8, pk[1]));
+    }
+  };
+
+  // ---- one hand-placed step.  Entering: sc = scores of half tile u with m_run settled for them,
+  // pw1 = packed probabilities of keys 16-31 of u-1 (their V^T in pbuf, half ptt), fr[0..1] = the
+  // V^T fragments dt = 0, 1 of that slice already on their way.  Leaving: sn / mn = scores and
+  // scaled row maxima of u+1 (K in kbuf, half ktt), pw1 = keys 16-31 of u (V^T in vbuf, half vtt),
+  // fr[0..1] = the first two fragments of the next step.
+  // LDS item n of a step: 0-3 V^T(pbuf, ptt, slice 1, dt n), 4-11 K(kbuf, ktt, ks n-4),
+  // 12-15 V^T(vbuf, vtt, slice 0, dt n-12), 16-17 V^T(vbuf, vtt, slice 1, dt n-16) for the next step.
+  bf16x8 fr[4];
+  const uint16_t* ld_kp = nullptr;  // source of the tile being loaded (STAGE 2)
+  auto step = [&](auto stage_tag, auto masked_tag, const char* pbuf, int ptt, const char* kbuf,
+                  int ktt, const char* vbuf, int vtt, char* wbuf, const f32x16 (&sc)[2],
+                  f32x16 (&sn)[2], float (&mn)[2], int next_tile) {
+    constexpr int STAGE = decltype(stage_tag)::value;
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    const float nm[2] = {-m_run[0], -m_run[1]};
+    float ps[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float pv[32];
+    u32x4 pw0[2];
+    // value v of 32: slice sh = v >> 4, row block rb = (v >> 3) & 1, element i = 8 sh + (v & 7)
+    auto fma_ = [&](int v) {
+      const int sh = v >> 4, rb = (v >> 3) & 1, i = 8 * sh + (v & 7);
+      pv[v] = __builtin_fmaf(sc[rb][i], scale_log2e, nm[rb]);
+      VPSA_PIN(pv[v]);
+    };
+    auto exp_ = [&](int v) {
+      pv[v] = __builtin_amdgcn_exp2f(pv[v]);
+      VPSA_PIN(pv[v]);
+    };
+    auto fin_ = [&](int v) {
+      const int sh = v >> 4, rb = (v >> 3) & 1;
+      ps[rb][v & 1] += pv[v];
+      VPSA_PIN(ps[rb][v & 1]);
+      if (v & 1) {
+        uint32_t w = pack_bf16x2(pv[v - 1], pv[v]);
+        VPSA_PIN(w);
+        if (sh == 0)
+          pw0[rb][(v & 7) >> 1] = w;
+        else
+          pw1[rb][(v & 7) >> 1] = w;
+      }
+    };
+    auto fetch = [&](int n) {
+      if (n < 4)
+        fr[n & 3] = v_frag(pbuf, ptt, 1, n);
+      else if (n < 12)
+        fr[n & 3] = k_frag(kbuf, ktt, n - 4);
+      else if (n < 16)
+        fr[n & 3] = v_frag(vbuf, vtt, 0, n - 12);
+      else
+        fr[n & 3] = v_frag(vbuf, vtt, 1, n - 16);
+    };
+    auto stage_op = [&](int i) {  // i = 0..7
+      if (STAGE == 1) {
+        if (i < 4)
+          *reinterpret_cast<u32x4*>(wbuf + wk_off[i]) = sk[i];
+        else
+          *reinterpret_cast<u32x4*>(wbuf + wv_off[i - 4]) = sv[i - 4];
+      } else if (STAGE == 2) {
+        if (i < 4)
+          sk[i] = *reinterpret_cast<const u32x4*>(ld_kp + i * 2048);
+        else
+          sv[i - 4] = *reinterpret_cast<const u32x4*>(ld_kp + v_offset + (i - 4) * 2048);
+      }
+    };
+    float mx[2][2];
+    float mfin[2];
+    // vector work of gap g (after MFMA g): finish value g, exponentiate g+1, fma of g+2 (values
+    // 24-31 get theirs in gaps 8-15), staging in 16-23, row maxima of sn in 25-31
+    auto gap = [&](int g) {
+      if (g + 1 < 32) exp_(g + 1);
+      if (g + 2 < 24) fma_(g + 2);
+      if (g >= 8 && g < 16) fma_(g + 16);
+      if (STAGE == 1 && g >= 16 && g < 24) stage_op(g - 16);
+      if (STAGE == 2 && g < 8) stage_op(g);
+      fin_(g);  // last: its exponential was issued a whole gap ago, no wait state is needed
+      if (!MASKED && g >= 25) {
+        const int rb_ = g >= 28 ? 1 : 0, st_ = (g - 25) % 3;
+        if (g <= 30) {
+          if (st_ == 0) {
+            mx[rb_][0] = max3_raw(sn[rb_][0], sn[rb_][1], sn[rb_][2]);
+            mx[rb_][1] = max3_raw(sn[rb_][3], sn[rb_][4], sn[rb_][5]);
+          } else if (st_ == 1) {
+            mx[rb_][0] = max3_raw(mx[rb_][0], sn[rb_][6], sn[rb_][7]);
+            mx[rb_][1] = max3_raw(mx[rb_][1], sn[rb_][8], sn[rb_][9]);
+            mx[rb_][0] = max3_raw(mx[rb_][0], sn[rb_][10], sn[rb_][11]);
+          } else {
+            mx[rb_][1] = max3_raw(mx[rb_][1], sn[rb_][12], sn[rb_][13]);
+            mx[rb_][0] = max3_raw(mx[rb_][0], sn[rb_][14], sn[rb_][15]);
+            mx[rb_][0] = max3_raw(mx[rb_][0], mx[rb_][1], mx[rb_][1]);
+          }
+        }
+        if (g == 28 || g == 31) {  // cross-half maximum and scaling of block 0 / 1
+          const int rb2_ = g == 28 ? 0 : 1;
+          const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx[rb2_][0]),
+                                                            __float_as_uint(mx[rb2_][0]), false, false);
+          mfin[rb2_] = max3_raw(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]), __uint_as_float(sw_[1])) *
+                       scale_log2e;
+          mfin[rb2_] = fmaxf(mfin[rb2_], NEG_BIG);
+          VPSA_PIN(mfin[rb2_]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // before the first MFMA: the first value's fma and exponential, the second's fma
+    fma_(0);
+    fma_(1);
+    exp_(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // gaps 0-7: pending slice (keys 16-31 of u-1)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      mfma_acc_agpr_now(o_acc[0][dt], fr[dt & 3], __builtin_bit_cast(bf16x8, pw1[0]));
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(dt + 2);
+      gap(2 * dt);
+      mfma_acc_agpr_now(o_acc[1][dt], fr[dt & 3], __builtin_bit_cast(bf16x8, pw1[1]));
+      __builtin_amdgcn_sched_barrier(0);
+      gap(2 * dt + 1);
+    }
+    // gaps 8-23: scores of u+1
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int n = 4 + ks;
+      if (ks == 0)
+        mfma_s_first(sn[0], fr[n & 3], qf[0][0]);
+      else
+        mfma_s_next(sn[0], fr[n & 3], qf[0][ks]);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(n + 2);
+      gap(8 + 2 * ks);
+      if (ks == 0)
+        mfma_s_first(sn[1], fr[n & 3], qf[1][0]);
+      else
+        mfma_s_next(sn[1], fr[n & 3], qf[1][ks]);
+      __builtin_amdgcn_sched_barrier(0);
+      gap(8 + 2 * ks + 1);
+    }
+    // gaps 24-31: keys 0-15 of u
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int n = 12 + dt;
+      mfma_acc_agpr_now(o_acc[0][dt], fr[n & 3], __builtin_bit_cast(bf16x8, pw0[0]));
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(n + 2);
+      gap(24 + 2 * dt);
+      mfma_acc_agpr_now(o_acc[1][dt], fr[n & 3], __builtin_bit_cast(bf16x8, pw0[1]));
+      __builtin_amdgcn_sched_barrier(0);
+      gap(24 + 2 * dt + 1);
+    }
+    l_run[0] += ps[0][0] + ps[0][1];
+    l_run[1] += ps[1][0] + ps[1][1];
+    if (MASKED) {
+      // tiles on the diagonal (at most two per block): mask and maxima after the matrix pipe drained
+      mfma_drain();
+      if (next_tile >= n_full) mask_half(next_tile, ktt, sn);
+      max_half(sn, mn);
+    } else {
+      mn[0] = mfin[0];
+      mn[1] = mfin[1];
+    }
+  };
+
+  // ring state: byte offsets of the buffers holding tile t, tile t+1, and tile t-1 (= the one
+  // that receives tile t+2)
+  int b_cur = 0, b_nxt = 32768, b_wr = 65536;
+
+  stage_load(0);
+  stage_write(lds);
+  // the first step multiplies an empty pending slice (pw1 = 0) by V^T of "tile -1": give that
+  // buffer finite contents
+  stage_write(lds + 65536);
+  stage_load(last < 1 ? last : 1);
+  stage_write(lds + 32768);
+  __syncthreads();
+
+  f32x16 sA[2], sB[2];
+  float mA[2], mB[2];
+  qk_half(lds, 0, sA);
+  if (n_full < 1) mask_half(0, 0, sA);
+  max_half(sA, mA);
+
+  // One 64-key tile = two steps.  Entering: sA / mA = scores and row maxima of (tile t, half 0).
+#define VPSA_V4_TILE(t, MASKED)                                                                 \
+  {                                                                                             \
+    {                                                                                           \
+      const int nt = (t) + 2;                                                                   \
+      const long page = bt[nt < last ? nt : last];                                              \
+      ld_kp = cache + page * page_stride + kv_head_off + tid * 8;                               \
+    }                                                                                           \
+    rescale(mA);                                                                                \
+    step(std::integral_constant<int, 2>{}, std::integral_constant<bool, MASKED>{}, lds + b_wr, 1, \
+         lds + b_cur, 1, lds + b_cur, 0, lds + b_wr, sA, sB, mB, (t));                          \
+    __syncthreads();                                                                            \
+    rescale(mB);                                                                                \
+    step(std::integral_constant<int, 1>{}, std::integral_constant<bool, MASKED>{}, lds + b_cur, 0, \
+         lds + b_nxt, 0, lds + b_cur, 1, lds + b_wr, sB, sA, mA, (t) + 1);                      \
+    const int tmp = b_wr;                                                                       \
+    b_wr = b_cur;                                                                               \
+    b_cur = b_nxt;                                                                              \
+    b_nxt = tmp;                                                                                \
+  }
+
+  // operands of the first step: V^T fragments of the (empty) pending slice
+  fr[0] = v_frag(lds + b_wr, 1, 1, 0);
+  fr[1] = v_frag(lds + b_wr, 1, 1, 1);
+
+  int t = 0;
+  const int n_fast = n_full - 1 < last ? n_full - 1 : last;
+  for (; t < n_fast; ++t) VPSA_V4_TILE(t, false)
+  for (; t < last; ++t) VPSA_V4_TILE(t, true)
+#undef VPSA_V4_TILE
+  // last tile (compiler-scheduled): the slice left pending by the steps, then both halves
+  {
+    mfma_drain();
+    if (last > 0) pv_slice(lds + b_wr, 1, 1, pw1);
+    u32x4 pk[2];
+    rescale(mA);
+    exp_slice(sA, 0, pk);
+    pv_slice(lds + b_cur, 0, 0, pk);
+    exp_slice(sA, 1, pk);
+    pv_slice(lds + b_cur, 0, 1, pk);
+    qk_half(lds + b_cur, 1, sB);
+    if (last >= n_full) mask_half(last, 1, sB);
+    max_half(sB, mB);
+    pw1[0] = (u32x4){0, 0, 0, 0};
+    pw1[1] = (u32x4){0, 0, 0, 0};
+    rescale(mB);
+    exp_slice(sB, 0, pk);
+    pv_slice(lds + b_cur, 1, 0, pk);
+    exp_slice(sB, 1, pk);
+    pv_slice(lds + b_cur, 1, 1, pk);
+  }
+
+  mfma_drain();
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const float l_tot = l_run[rb] + __shfl_xor(l_run[rb], 32, 64);
+    if (row_ok[rb]) {
+      const float inv = 1.f / l_tot;
+      uint16_t* op = out + (long)(row0 + my_row[rb]) * out_stride + head * HEAD_DIM;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          u32x2 w;
+          w[0] = pack_bf16x2(o_acc[rb][dt][4 * g4] * inv, o_acc[rb][dt][4 * g4 + 1] * inv);
+          w[1] = pack_bf16x2(o_acc[rb][dt][4 * g4 + 2] * inv, o_acc[rb][dt][4 * g4 + 3] * inv);
+          *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g4 + 4 * h) = w;
+        }
+    }
+  }
+}
+
 // Kernel selection.  -1 = automatic: the kernel follows the tile height the host built its work
 // list for (64 rows: third generation; 32 * (4 / GP) rows: second generation), head-major tile
 // order when sequences have many q-tiles.  Fixed choices are for A/B timing and tests:
 // 0 = first generation, 1 = generation 2 without wave priorities, 2 = generation 2,
 // 3 = generation 2 head-major, 4 = generation 3, 5 = generation 3 head-major, 6 / 7 = as 4 / 5
-// without the instruction-interleave hints.
+// without the instruction-interleave hints, 8 = generation 4, 9 = generation 4 head-major.
 static int g_prefill_variant = -1;
 VPSA_EXPORT int vpsa_set_prefill_variant(int v) {
   const int old = g_prefill_variant;
@@ -1041,18 +1536,26 @@ VPSA_EXPORT int vpsa_paged_prefill(const void* q, long q_stride, void* out, long
     if (variant >= 0 && variant < 4) return -2;
     static bool attr_set = false;
     if (!attr_set) {
-      const void* fns[4] = {(const void*)paged_prefill_kernel_v3<false, 1>,
+      const void* fns[6] = {(const void*)paged_prefill_kernel_v3<false, 1>,
                             (const void*)paged_prefill_kernel_v3<true, 1>,
                             (const void*)paged_prefill_kernel_v3<false, 0>,
-                            (const void*)paged_prefill_kernel_v3<true, 0>};
+                            (const void*)paged_prefill_kernel_v3<true, 0>,
+                            (const void*)paged_prefill_kernel_v4<false>,
+                            (const void*)paged_prefill_kernel_v4<true>};
       for (const void* f : fns)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 98304) != hipSuccess)
           return -3;
       attr_set = true;
     }
     dim3 grid(num_tiles, n_kv * (G / 4)), block(256);
-    if (variant < 0) variant = many_tiles ? 5 : 4;
-    if (variant == 5) {
+    if (variant < 0) variant = many_tiles ? 9 : 8;
+    if (variant == 9) {
+      hipLaunchKernelGGL((paged_prefill_kernel_v4<true>), grid, block, 98304, stream,
+                         VPSA_PREFILL_ARGS);
+    } else if (variant == 8) {
+      hipLaunchKernelGGL((paged_prefill_kernel_v4<false>), grid, block, 98304, stream,
+                         VPSA_PREFILL_ARGS);
+    } else if (variant == 5) {
       hipLaunchKernelGGL((paged_prefill_kernel_v3<true, 1>), grid, block, 98304, stream,
                          VPSA_PREFILL_ARGS);
     } else if (variant == 4) {

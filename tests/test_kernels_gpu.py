@@ -129,7 +129,7 @@ def _run_prefill(q, pool, layer, bt, q_lens, ctx, n_q, n_kv, variant, hd=128):
     return out, cu, ctx_t, rows
 
 
-@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("n_q,n_kv", [(32, 8), (8, 8), (8, 4), (16, 2), (28, 4), (10, 2), (12, 2)])
 def test_paged_prefill_matches_reference(n_q, n_kv, variant):
     if not _prefill_variant_ok(variant, n_q, n_kv):
@@ -153,7 +153,7 @@ def test_paged_prefill_matches_reference(n_q, n_kv, variant):
     assert err < REL_TOL, err
 
 
-@pytest.mark.parametrize("variant", [2, 4])
+@pytest.mark.parametrize("variant", [2, 4, 8])
 def test_paged_prefill_forced_rescale(variant):
     """A key far larger than the rest late in the context forces the online-softmax
     rescale branch on a chosen tile (in the second half of the tile for the 64-row kernel)."""
@@ -194,7 +194,7 @@ def _ref_prefill_long(q, pool, layer, bt_row, ql, ctx, n_q, n_kv, hd):
     return out
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 8, 9])
 @pytest.mark.parametrize("ql,prefix", [(4616, 16384), (1024, 15360)])
 def test_paged_prefill_long_context(ql, prefix, variant):
     """The last chunk of a 21k-token prompt (4616 rows behind 16384 cached keys, 329 pages deep in

@@ -217,7 +217,7 @@ class ModelRunner:
             meta.pre_ctx_lens = self._to_dev(plan["pre_ctx"], torch.int32)
             if self.device.type == "cuda":
                 rows = ops.prefill_tile_rows(q_lens, self.model.n_q, self.model.n_kv)
-                ts, tq = ops.build_prefill_tiles(q_lens, self.model.n_q, self.model.n_kv, rows)
+                ts, tq = ops.build_prefill_tiles(q_lens, self.model.n_q, self.model.n_kv, rows, plan["pre_ctx"])
                 meta.pre_tile_rows = rows
                 meta.pre_tile_seq = self._to_dev(ts, torch.int32)
                 meta.pre_tile_q0 = self._to_dev(tq, torch.int32)

@@ -228,18 +228,21 @@ def prefill_tile_rows(q_lens, n_q, n_kv) -> int:
     return rows
 
 
-def build_prefill_tiles(q_lens, n_q, n_kv, rows=None):
+def build_prefill_tiles(q_lens, n_q, n_kv, rows=None, ctx_lens=None):
     """Host-side work list for the prefill kernel: one (sequence, first row) entry per query
-    tile of ``rows`` rows (default: ``prefill_tile_rows``), longest-context tiles first so the
-    heaviest workgroups start earliest."""
+    tile of ``rows`` rows (default: ``prefill_tile_rows``).  Sequences with the longest context
+    come first (the heaviest workgroups start earliest) and a sequence's tiles stay together,
+    longest first: the workgroups that run side by side on one XCD then stream the SAME K/V
+    pages through its L2 instead of one stream per sequence (8 equal sequences interleaved cost
+    the kernel a fifth of its throughput in HBM waits)."""
     qt = rows or prefill_tile_rows(q_lens, n_q, n_kv)
+    weight = ctx_lens if ctx_lens is not None else q_lens
     seqs, q0s = [], []
-    for s, ql in enumerate(q_lens):
-        for q0 in range(0, ql, qt):
+    for s in sorted(range(len(q_lens)), key=lambda i: -weight[i]):
+        for q0 in range((q_lens[s] - 1) // qt * qt, -1, -qt):
             seqs.append(s)
             q0s.append(q0)
-    order = sorted(range(len(seqs)), key=lambda i: -q0s[i])
-    return [seqs[i] for i in order], [q0s[i] for i in order]
+    return seqs, q0s
 
 
 def paged_prefill(q, out, pool, layer, block_tables, cu_q, ctx_lens, tile_seq, tile_q0, n_q, n_kv,
