@@ -353,3 +353,34 @@ def test_cloud_scripts_parse_and_share_the_common_tail():
     for tf in CLOUD.glob("terraform/**/*.tf"):
         body = tf.read_text()
         assert body.count("{") == body.count("}"), tf
+
+
+def _workload_literals(objs):
+    """Every command-line flag and every environment variable name that the renderer gives to any
+    container of any workload."""
+    flags, envs = set(), set()
+    for o in objs:
+        if o["kind"] not in ("Deployment", "StatefulSet"):
+            continue
+        pod = o["spec"]["template"]["spec"]
+        for c in pod.get("containers", []) + pod.get("initContainers", []):
+            for word in list(c.get("command") or []) + list(c.get("args") or []):
+                flags |= set(re.findall(r"(?<![\w-])--[a-z][a-z0-9-]*", str(word)))
+            for e in c.get("env") or []:
+                envs.add(e["name"])
+    return flags, envs
+
+
+@pytest.mark.parametrize("path", EXAMPLES, ids=lambda p: p.stem)
+def test_chart_names_every_flag_and_env_the_renderer_emits(path):
+    """The chart and the Python renderer implement one contract twice.  No `helm` binary exists
+    here to render the Go templates, so drift is caught literally: whatever flag or environment
+    variable the renderer emits for an example must be spelled out in the chart's templates,
+    unless it comes straight from the example's own values (extra args, user env)."""
+    chart = "\n".join(p.read_text() for p in (ROOT / "deploy/helm/templates").glob("*"))
+    own = path.read_text()
+    flags, envs = _workload_literals(_objs(path))
+    missing_flags = sorted(f for f in flags if f not in chart and f not in own)
+    missing_envs = sorted(e for e in envs if e not in chart and e not in own)
+    assert not missing_flags, f"{path.name}: flags the chart never emits: {missing_flags}"
+    assert not missing_envs, f"{path.name}: env names the chart never emits: {missing_envs}"
