@@ -117,7 +117,7 @@ def decode_case(n_seqs: int, ctx: int, iters: int) -> dict:
             ops.set_decode_variant(dv)
             ms = timed(run, iters)
             entry[f"v{dv}"] = {"ms": round(ms, 4), "tb_per_s": round(kv_bytes / ms / 1e9, 3)}
-        ops.set_decode_variant(0)
+        ops.set_decode_variant(-1)
         res[f"splits{splits}"] = entry
     res["default_splits"] = ops.decode_num_splits(n_seqs, N_KV, ctx)
     return res

@@ -143,18 +143,18 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(
       }
       if (h >= n_q && slot >= 0) {
         const int kvh = h - n_q;
-        uint32_t* kd =
-            reinterpret_cast<uint32_t*>(kpage + ((long)kvh * PAGE + off) * HEAD_DIM);
-        kd[j] = lo;
-        kd[32 + j] = hi;
+        // channels 2j, 2j+1 and 64 + 2j, 65 + 2j of key `off` (K part: [channel block][key][32])
+        uint16_t* kd = kpage + (long)kvh * PAGE * HEAD_DIM;
+        *reinterpret_cast<uint32_t*>(kd + k_elem_off(off, 2 * j)) = lo;
+        *reinterpret_cast<uint32_t*>(kd + k_elem_off(off, 64 + 2 * j)) = hi;
       }
     } else if (slot >= 0) {
       const int kvh = h - n_q - n_kv;
-      uint16_t* vd = vpage + (long)kvh * HEAD_DIM * PAGE + off;
-      vd[(2 * j) * PAGE] = (uint16_t)(lo & 0xffff);
-      vd[(2 * j + 1) * PAGE] = (uint16_t)(lo >> 16);
-      vd[(64 + 2 * j) * PAGE] = (uint16_t)(hi & 0xffff);
-      vd[(65 + 2 * j) * PAGE] = (uint16_t)(hi >> 16);
+      uint16_t* vd = vpage + (long)kvh * HEAD_DIM * PAGE;  // V part: [key half][channel][32 keys]
+      vd[v_elem_off(2 * j, off)] = (uint16_t)(lo & 0xffff);
+      vd[v_elem_off(2 * j + 1, off)] = (uint16_t)(lo >> 16);
+      vd[v_elem_off(64 + 2 * j, off)] = (uint16_t)(hi & 0xffff);
+      vd[v_elem_off(65 + 2 * j, off)] = (uint16_t)(hi >> 16);
     }
   }
 }

@@ -62,11 +62,11 @@ VPSA_EXPORT int vpsa_kv_scatter_pages(const void* staging, const long* page_ids,
 // CacheGen-style codec front end.
 // The staging buffer is a sequence of units of `unit_elems` = n_kv*64*128 elements that
 // alternate K, V per layer:  unit u -> layer (u/2) % n_layers, K when u is even.
-// A group is 64 consecutive elements (half of a key's channels in a K unit; one channel
-// over the page's 64 tokens in a V unit) and carries one fp32 scale.
-//   * K groups are delta-coded against the same channels of the page's first token
+// A group is 64 consecutive elements (32 channels of two consecutive keys in a K unit; two
+// channels over 32 of the page's tokens in a V unit) and carries one fp32 scale.
+//   * K groups are delta-coded against the same channels of the page's first two tokens
 //     (token locality), using the anchor's *dequantised* value so errors do not chain;
-//   * V groups are quantised directly (per-channel scale);
+//   * V groups are quantised directly;
 //   * the number of quantisation levels depends on the layer (`levels[layer]`, e.g. 127
 //     for early layers and 15 or 7 for late ones): the symbols always occupy one byte
 //     here, and the host range coder turns the narrower alphabets into fewer bits.
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void cachegen_encode_kernel(
   const long gin = g - unit * groups_per_unit;
   const bool is_k = (unit & 1) == 0;
   const float L = (float)levels[(unit >> 1) % n_layers];
-  const int tok = is_k ? (int)((gin >> 1) & 63) : 0;
-  const long ganchor = g - (long)tok * 2;
+  const int tok = is_k ? (int)(gin & 31) : 0;  // key pair within the channel block
+  const long ganchor = g - (long)tok;
 
   float x[8], a[8];
   unpack8(*reinterpret_cast<const u32x4*>(staging + g * 64 + sub * 8), x);
@@ -148,8 +148,8 @@ __global__ __launch_bounds__(256) void cachegen_decode_kernel(
   const long unit = gid / groups_per_unit;
   const long gin = gid - unit * groups_per_unit;
   const bool is_k = (unit & 1) == 0;
-  const int tok = is_k ? (int)((gin >> 1) & 63) : 0;
-  const long ganchor = gid - (long)tok * 2;
+  const int tok = is_k ? (int)(gin & 31) : 0;
+  const long ganchor = gid - (long)tok;
   const u32x2 qa = *reinterpret_cast<const u32x2*>(symbols + ganchor * 64 + sub * 8);
   const float sa = scales[ganchor];
   float v[8];

@@ -89,8 +89,9 @@ def _v_offset_pool(pages, layers, n_kv, hd=128, seed=0):
     pool = _pool(pages, layers, n_kv, hd, seed)
     g = torch.Generator(device=DEV).manual_seed(seed + 1000)
     off = (torch.rand(hd, device=DEV, generator=g) * 4 - 2)
-    v = pool[:, :, 1].view(pages, layers, n_kv, hd, ops.PAGE).float()
-    v += off[None, None, None, :, None]
+    # V part of a KV head: [key half][channel][32 keys]
+    v = pool[:, :, 1].view(pages, layers, n_kv, ops.PAGE // 32, hd, 32).float()
+    v += off[None, None, None, None, :, None]
     pool[:, :, 1] = v.view(pages, layers, n_kv, hd * ops.PAGE).to(BF)
     return pool
 
@@ -165,11 +166,11 @@ def test_paged_prefill_forced_rescale(variant):
     pool = _v_offset_pool(max_pages + 1, 1, n_kv, seed=8)
     bt = _block_tables(1, max_pages, pool.shape[0], 9)
     q = torch.randn(ql, n_q * hd, device=DEV).to(BF)
-    kview = pool[:, 0, 0].view(pool.shape[0], n_kv, ops.PAGE, hd)
+    kview, _ = ref._kv_views(pool, 0, n_kv, hd)  # [pages, n_kv, PAGE, channel blocks, 32]
     # spikes: key 300 aligned with query row 10, key 360 (second half of its page) with row 40
     for key, row, gain in ((300, 10, 4.0), (360, 40, 6.0)):
         page, off = int(bt[0, key // ops.PAGE]), key % ops.PAGE
-        kview[page, :, off, :] = (q[row].view(n_kv, 4, hd)[:, 0, :].float() * gain).to(BF)
+        kview[page, :, off] = (q[row].view(n_kv, 4, hd)[:, 0, :].float() * gain).to(BF).view(n_kv, hd // 32, 32)
     out, cu, ctx_t, _ = _run_prefill(q, pool, 0, bt, [ql], [ctx], n_q, n_kv, variant)
     out_ref = torch.zeros_like(q)
     ref.paged_prefill(q, out_ref, pool, 0, bt, cu, ctx_t, n_q, n_kv, hd, 1.0 / math.sqrt(hd))

@@ -122,7 +122,9 @@ class KVConnector:
         ident = "|".join(str(x) for x in (
             engine.cfg.model, engine.cfg.model_name, runner.dtype, mc.num_layers, mc.hidden_size,
             runner.kv_head_dim if hasattr(runner, "kv_head_dim") else mc.head_dim, f"tp{tp.rank}of{tp.size}", f"pp{pp.rank}of{pp.size}",
-            getattr(engine.cfg, "kv_namespace", "") or ""))
+            getattr(engine.cfg, "kv_namespace", "") or "",
+            "page-layout-2"))  # in-page K/V order (blocks of 32 channels / 32 keys): pages written under
+        #                        another order must never be read back
         return hashlib.sha1(ident.encode()).hexdigest()[:12]
 
     def _key(self, h: int) -> bytes:

@@ -57,9 +57,9 @@ def set_prefill_variant(v: int) -> int:
 
 
 def set_decode_variant(v: int) -> int:
-    """Select the decode attention kernel (0: one register set per wave, 1: software-pipelined
-    with two register sets, 2: a wave takes both halves of a page).  Returns the previous
-    selection."""
+    """Select the decode attention kernel (-1: automatic by split count, 0: one register set per
+    wave, 1: software-pipelined with two register sets, 2: a wave takes both halves of a page).
+    Returns the previous selection."""
     return int(_kernels().vpsa_set_decode_variant(c_int(v)))
 
 
@@ -270,9 +270,9 @@ def paged_prefill(q, out, pool, layer, block_tables, cu_q, ctx_lens, tile_seq, t
 
 
 def decode_num_splits(num_seqs: int, n_kv: int, max_ctx: int) -> int:
-    """Enough workgroups to cover 256 CUs five times over (measured best at 40 sequences x 8 KV
-    heads x 21.5k keys: 4 splits = 1280 workgroups read 5.7 TB/s, 3 splits 5.6, 1 split 4.3), at
-    least 256 keys per split."""
+    """Enough workgroups to cover 256 CUs five times over (measured at 40 sequences x 8 KV heads x
+    21.5k keys: 4 splits = 1280 workgroups read 5.95 TB/s with the pipelined kernel, 3 splits the
+    same, 1 split 5.7), at least 256 keys per split."""
     want = max(1, -(-1280 // max(1, num_seqs * n_kv)))
     by_len = max(1, max_ctx // 256)
     return int(max(1, min(want, by_len, 32)))

@@ -4,8 +4,12 @@ These are the numerical oracles for the HIP kernels in ``csrc/kernels`` and the 
 path for CPU tensors (unit tests, CPU-only plumbing replicas).  They share the paged
 KV-cache layout with the kernels:
 
-    pool[page, layer, 0, kv_head]  viewed as  [PAGE, head_dim]   (K, one row per key)
-    pool[page, layer, 1, kv_head]  viewed as  [head_dim, PAGE]   (V, transposed)
+    pool[page, layer, 0, kv_head]  viewed as  [head_dim / 32, PAGE, 32]   (K: channel block, key, channel)
+    pool[page, layer, 1, kv_head]  viewed as  [PAGE / 32, head_dim, 32]   (V: key half, channel, key)
+
+(blocks of 32 = 64 bytes, so that a 16-row MFMA fragment load of the decode kernel is one
+contiguous KiB; head sizes that are not a multiple of 32 use one block of the whole head).
+``_kv_views`` presents both as [.., PAGE, head_dim] / [.., head_dim, PAGE] whatever the blocks.
 """
 
 from __future__ import annotations
@@ -50,9 +54,13 @@ def build_cos_sin(head_dim: int, max_pos: int, theta: float, scaling: dict | Non
 
 
 def _kv_views(pool, layer, n_kv, head_dim):
-    k = pool[:, layer, 0].view(pool.shape[0], n_kv, PAGE, head_dim)
-    v = pool[:, layer, 1].view(pool.shape[0], n_kv, head_dim, PAGE)
-    return k, v
+    """K as [pages, n_kv, PAGE, head_dim] and V as [pages, n_kv, head_dim, PAGE]: permuted views of
+    the pool (reads and indexed writes go through to it)."""
+    cb = 32 if head_dim % 32 == 0 else head_dim
+    n = pool.shape[0]
+    k = pool[:, layer, 0].view(n, n_kv, head_dim // cb, PAGE, cb).permute(0, 1, 3, 2, 4)
+    v = pool[:, layer, 1].view(n, n_kv, PAGE // 32, head_dim, 32).permute(0, 1, 3, 2, 4)
+    return k, v  # [n, n_kv, PAGE, blocks, cb], [n, n_kv, head_dim, 2, 32]
 
 
 def rope_and_cache(qkv, positions, slots, cos_sin, pool, layer, n_q, n_kv, head_dim, rotary=True):
@@ -75,16 +83,19 @@ def rope_and_cache(qkv, positions, slots, cos_sin, pool, layer, n_q, n_kv, head_
     ok = slots >= 0
     s = slots[ok].long()
     page, off = s // PAGE, s % PAGE
-    kview[page, :, off, :] = x[ok, n_q : n_q + n_kv]
-    vview[page, :, :, off] = x[ok, n_q + n_kv :]
+    cb = kview.shape[-1]
+    kview[page, :, off] = x[ok, n_q : n_q + n_kv].reshape(-1, n_kv, head_dim // cb, cb)
+    vview[page, :, :, off // 32, off % 32] = x[ok, n_q + n_kv :]
 
 
 def _gather_kv(pool, layer, n_kv, head_dim, block_row, length):
     kview, vview = _kv_views(pool, layer, n_kv, head_dim)
     npages = (length + PAGE - 1) // PAGE
     pages = block_row[:npages].long()
-    k = kview[pages].permute(1, 0, 2, 3).reshape(n_kv, npages * PAGE, head_dim)[:, :length]
-    v = vview[pages].permute(1, 2, 0, 3).reshape(n_kv, head_dim, npages * PAGE)[:, :, :length]
+    k = kview[pages].reshape(npages, n_kv, PAGE, head_dim).permute(1, 0, 2, 3).reshape(
+        n_kv, npages * PAGE, head_dim)[:, :length]
+    v = vview[pages].reshape(npages, n_kv, head_dim, PAGE).permute(1, 2, 0, 3).reshape(
+        n_kv, head_dim, npages * PAGE)[:, :, :length]
     return k.float(), v.float().transpose(1, 2)
 
 
@@ -153,8 +164,8 @@ def cachegen_encode(staging, levels, unit_elems, n_layers):
     gin = gidx % gpu
     is_k = (unit % 2) == 0
     lv = torch.as_tensor(levels, device=flat.device, dtype=torch.float32)[(unit // 2) % n_layers][:, None]
-    tok = torch.where(is_k, (gin // 2) % 64, torch.zeros_like(gin))
-    anchor = x[gidx - tok * 2]
+    tok = torch.where(is_k, gin % 32, torch.zeros_like(gin))  # key pair within the channel block
+    anchor = x[gidx - tok]
     amax = anchor.abs().amax(-1, keepdim=True)
     sa = torch.where(amax > 0, amax / lv, torch.ones_like(amax))
     qa = torch.round(anchor / sa)
@@ -176,8 +187,8 @@ def cachegen_decode(symbols, scales, unit_elems, dtype=torch.bfloat16):
     unit = gidx // gpu
     gin = gidx % gpu
     is_k = (unit % 2) == 0
-    tok = torch.where(is_k, (gin // 2) % 64, torch.zeros_like(gin))
-    a = gidx - tok * 2
+    tok = torch.where(is_k, gin % 32, torch.zeros_like(gin))
+    a = gidx - tok
     base = q[a] * scales[a][:, None]
     delta = torch.where((tok == 0)[:, None], torch.zeros_like(q), q * scales[:, None])
     return (base + delta).to(dtype).view(-1)
