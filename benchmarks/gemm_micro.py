@@ -60,11 +60,14 @@ def main():
     ap.add_argument("--rows", default="1,4,8,16,24,32,40,64")
     ap.add_argument("--variants", default="0")
     ap.add_argument("--shapes", default=",".join(SHAPES))
+    ap.add_argument("--packed", action="store_true", help="also time the pre-packed-weight kernel")
+    ap.add_argument("--packed-targets", default="512", help="workgroup targets to try for its split count")
+    ap.add_argument("--no-probe", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    buf = torch.empty(4 << 30, dtype=torch.uint8, device=dev).random_(0, 255)
-    for blocks in (1024, 2048, 4096, 8192):
+    buf = torch.empty((64 << 20) if a.no_probe else (4 << 30), dtype=torch.uint8, device=dev).random_(0, 255)
+    for blocks in (() if a.no_probe else (1024, 2048, 4096, 8192)):
         t = timed(lambda i=0: ops.hbm_read_probe(buf, blocks), 10, graph=False)
         print(json.dumps({"case": "hbm_read_probe", "blocks": blocks, "GB": 4.295,
                           "TB_per_s": round(buf.numel() / t / 1e12, 3)}), flush=True)
@@ -117,6 +120,21 @@ def main():
                 row[f"s{v}_TB_per_s"] = round(wbytes / t / 1e12, 2)
                 row[f"s{v}_rel_err"] = round(err, 5)
             ops.set_gemm_variant(0)
+            if a.packed and ops.packed_supported(n, k, pair):  # pre-packed weights, register-direct
+                wps = [ops.pack_weight(w) for w in ws]
+                for target in [int(t) for t in a.packed_targets.split(",")]:
+                    ops.set_packed_target(target)
+
+                    def packed(i=0):
+                        return ops.packed_linear(x, wps[i % copies], n, k, None, pair)
+
+                    got = packed(0)
+                    err = float((got.float() - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
+                    t = timed(packed, iters)
+                    row[f"p{target}_us"] = round(t * 1e6, 1)
+                    row[f"p{target}_TB_per_s"] = round(wbytes / t / 1e12, 2)
+                    row[f"p{target}_rel_err"] = round(err, 5)
+                del wps
             print(json.dumps(row), flush=True)
         del ws
 

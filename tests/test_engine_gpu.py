@@ -368,3 +368,24 @@ def test_penalties_join_the_batched_kernels_on_gpu():
     assert len(set(outs[2])) == len(outs[2]) == 24
     rep = eng.generate([ps[1]], SamplingParams(max_tokens=24, temperature=0, repetition_penalty=1.5, ignore_eos=True))[0]
     assert rep != eng.generate([ps[1]], copy.deepcopy(plain))[0] or len(set(rep)) == 24
+
+
+def test_packed_decode_weights_option_serves_the_same_model():
+    """--packed-decode-weights on: decode-only steps stream a second, tile-ordered copy of the MLP
+    matrices.  Same model: greedy tokens agree with the default engine except at near-ties, the
+    copies exist for every layer, sleeping drops them and waking rebuilds them."""
+    ps = prompts(4, 90, seed=21)
+    sp = SamplingParams(max_tokens=8, temperature=0, ignore_eos=True)
+    base = gpu_engine("tiny-llama-gqa").generate(ps, copy.deepcopy(sp))
+    eng = gpu_engine("tiny-llama-gqa", packed_decode_weights="on", enable_sleep_mode=True)
+    m = eng.runner.model
+    assert all(lw.w_gate_up_p is not None and lw.w_down_p is not None for lw in m.layers)
+    n_weights = len(list(m.weight_tensors()))
+    got = eng.generate(ps, copy.deepcopy(sp))
+    agree = sum(a[:4] == b[:4] for a, b in zip(got, base))
+    assert agree >= 3, (got, base)
+    freed = eng.sleep(1)
+    assert freed > 0 and not list(m.packed_tensors())
+    eng.wake_up()
+    assert len(list(m.packed_tensors())) == 2 * len(m.layers) and len(list(m.weight_tensors())) == n_weights
+    assert eng.generate(ps, copy.deepcopy(sp)) == got

@@ -319,6 +319,38 @@ def test_stream_gemm_matches_fp32(m, n, k, bias, pair, variant):
     assert torch.equal(got, again), "the split reduction must be reproducible"
 
 
+@pytest.mark.parametrize("m", [1, 7, 16, 17, 40, 48, 64])
+@pytest.mark.parametrize("n,k,bias,pair", [(6144, 4096, False, False), (4096, 14336, False, False),
+                                           (1536, 1024, True, False), (128, 256, True, False),
+                                           (2 * 14336, 4096, False, True), (2 * 64, 512, False, True),
+                                           (64, 384, False, False)])
+def test_packed_gemm_matches_fp32(m, n, k, bias, pair):
+    """Projection over weights pre-packed in matrix-core tile order (register-direct weight
+    stream, split reduction + fixed-order combine) against fp32; a row's bits do not depend on
+    what else is in the batch."""
+    torch.manual_seed(m * 11 + n)
+    x = torch.randn(m, k, device=DEV).to(BF)
+    w = (torch.randn(n, k, device=DEV) * 0.03).to(BF)
+    b = torch.randn(n, device=DEV).to(BF) if bias else None
+    wp = ops.pack_weight(w)
+    assert ops.packed_supported(n, k, pair)
+    got = ops.packed_linear(x, wp, n, k, b, pair)
+    again = ops.packed_linear(x, wp, n, k, b, pair)
+    assert got is not None
+    want = torch.nn.functional.linear(x.float(), w.float(), None if b is None else b.float())
+    if pair:
+        want = torch.nn.functional.silu(want[:, : n // 2]) * want[:, n // 2:]
+    assert got.shape == want.shape
+    err = (got.float() - want).abs().max().item() / want.abs().max().item()
+    assert err < 1e-2, err
+    assert torch.equal(got, again), "the split reduction must be reproducible"
+    alone = ops.packed_linear(x[:1].contiguous(), wp, n, k, b, pair)
+    assert torch.equal(alone[0], got[0]), "row 0 alone and inside the batch"
+    # the public entry points take the packed copy
+    via = ops.gate_up_silu(x, w, wp) if pair else ops.linear(x, w, b, wp)
+    assert torch.equal(via, got)
+
+
 def test_skinny_linear_strided_rows_and_fallback():
     torch.manual_seed(3)
     base = torch.randn(9, 2 * 4096, device=DEV).to(BF)

@@ -55,6 +55,9 @@ def build_parser() -> argparse.ArgumentParser:
     s.add_argument("--kv-transfer-config", default=None)
     s.add_argument("--swap-space", type=float, default=0.0)
     s.add_argument("--enforce-eager", action="store_true")
+    s.add_argument("--packed-decode-weights", choices=("auto", "on", "off"), default="off",
+                   help="second copy of the dense MLP matrices in matrix-core tile order for decode steps "
+                        "(auto: when it costs at most a tenth of the card's memory)")
     s.add_argument("--prefill-step-ms", type=float, default=30.0,
                    help="latency-aware prefill admission: estimated prefill time per step (0 = token budget only)")
     s.add_argument("--seed", type=int, default=0)
@@ -86,6 +89,7 @@ def config_from_args(args: argparse.Namespace) -> EngineConfig:
         kv_transfer=KVTransferConfig.from_json(args.kv_transfer_config),
         kv_offload=KVOffloadConfig.from_env(), swap_space=args.swap_space,
         enforce_eager=args.enforce_eager, seed=args.seed, prefill_step_ms=args.prefill_step_ms,
+        packed_decode_weights=args.packed_decode_weights,
         api_key=args.api_key or os.environ.get("VLLM_API_KEY") or None,
         disable_log_requests=args.disable_log_requests, trust_remote_code=args.trust_remote_code,
         task=args.task, load_format=args.load_format)

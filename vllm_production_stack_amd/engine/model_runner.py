@@ -55,6 +55,7 @@ class ModelRunner:
                                  cfg.seed, cfg.load_format)
         log.info("model %s ready: %.2f GiB weights in %.1fs", model_cfg.name,
                  self.model.weight_bytes() / 2**30, time.time() - t0)
+        self._pack_decode_weights()
         self.n_kv_local = self.model.n_kv
         self.replica = get_replica()
         self.distributed = self.replica.size > 1
@@ -82,6 +83,15 @@ class ModelRunner:
         self._sleep_stash: list[tuple[torch.Tensor, torch.Tensor]] = []
         # host-side seconds of eager steps: plan lists, device tensors, kernel launches
         self.t_plan = self.t_materialize = self.t_launch = 0.0
+
+    def _pack_decode_weights(self) -> None:
+        mode = getattr(self.cfg, "packed_decode_weights", "off")
+        if mode == "off" or self.device.type != "cuda" or not hasattr(self.model, "pack_decode_weights"):
+            return
+        total = torch.cuda.mem_get_info(self.device)[1]
+        used = self.model.pack_decode_weights(total if mode == "on" else total // 10)
+        if used:
+            log.info("decode-step copy of the MLP weights in matrix-core tile order: %.2f GiB", used / 2**30)
 
     def _tp_graphs_ready(self) -> bool:
         """Tensor-parallel replicas (no pipeline stages) replay decode graphs on every rank when
@@ -343,6 +353,8 @@ class ModelRunner:
         stores = [self.pool] if self.pool is not None else []
         if self.model is not None and hasattr(self.model, "weight_tensors"):
             stores += list(self.model.weight_tensors())
+        if self.model is not None and hasattr(self.model, "packed_tensors"):
+            stores += list(self.model.packed_tensors())
         for t in stores:
             try:
                 t.untyped_storage().resize_(0)
@@ -545,6 +557,10 @@ class ModelRunner:
         self._row_track.clear()
         self._graph_pool = None
         if self.device.type == "cuda":
+            if hasattr(self.model, "drop_packed"):
+                packed_bytes = sum(t.numel() * t.element_size() for t in self.model.packed_tensors())
+                self.model.drop_packed()  # derived copies: rebuilt from the weights on wake-up
+                freed += packed_bytes
             for t in self.model.weight_tensors():
                 host = None
                 if level == 1:
@@ -580,6 +596,7 @@ class ModelRunner:
             torch.cuda.synchronize()
             if any(h is None for _, h in self._sleep_stash):
                 self.model.init_random(self.cfg.seed)
+            self._pack_decode_weights()
         self._sleep_stash = []
         self.pool = torch.zeros(self._pool_shape, dtype=self.dtype, device=self.device)
         self.sleeping = False

@@ -34,7 +34,8 @@ def _kernels():
             "vpsa_moe_gemv", "vpsa_moe_mfma", "vpsa_lora_shrink", "vpsa_lora_expand",
             "vpsa_skinny_gemm", "vpsa_hbm_read_probe", "vpsa_set_gemm_variant", "vpsa_stream_gemm",
             "vpsa_stream_gemm_splits", "vpsa_set_stream_targets", "vpsa_rans_encode", "vpsa_rans_pack",
-            "vpsa_rans_decode", "vpsa_sample", "vpsa_grouped_gemm",
+            "vpsa_rans_decode", "vpsa_sample", "vpsa_grouped_gemm", "vpsa_packed_gemm",
+            "vpsa_packed_gemm_splits", "vpsa_set_packed_target",
         ):
             getattr(lib, name).restype = c_int
         if os.environ.get("VPSA_PREFILL_VARIANT"):  # pin one prefill kernel for A/B runs
@@ -343,6 +344,39 @@ def _stream_gemm(x2, w, bias, pair):
     return out if rc == 0 else None
 
 
+def pack_weight(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] -> the same matrix in matrix-core tile order, [N / 16][K / 32][16][32] flattened
+    (N a multiple of 16, K of 32): what ``packed_linear`` streams.  A second copy of the weight."""
+    n, k = w.shape
+    assert n % 16 == 0 and k % 32 == 0
+    return w.view(n // 16, 16, k // 32, 32).permute(0, 2, 1, 3).contiguous().view(-1)
+
+
+def set_packed_target(workgroups: int) -> int:
+    """Workgroups (row blocks x reduction slices) the packed kernel aims for; returns the previous value."""
+    return int(_kernels().vpsa_set_packed_target(c_int(workgroups)))
+
+
+def packed_supported(n: int, k: int, pair: bool = False) -> bool:
+    return int(_kernels().vpsa_packed_gemm_splits(c_int(n), c_int(k), c_int(1 if pair else 0))) > 0
+
+
+def packed_linear(x2, wp, n: int, k: int, bias=None, pair: bool = False):
+    """y = x2 @ W.T (+ bias), or silu(x2 @ Wg.T) * (x2 @ Wu.T) for ``pair`` (W = [Wg; Wu]), with W
+    given as ``pack_weight(W)``; up to 64 rows.  ``None`` when the kernel does not tile the shape."""
+    lib = _kernels()
+    m = x2.shape[0]
+    splits = int(lib.vpsa_packed_gemm_splits(c_int(n), c_int(k), c_int(1 if pair else 0)))
+    if splits <= 0 or m > 64:
+        return None
+    out = torch.empty((m, n // 2 if pair else n), dtype=x2.dtype, device=x2.device)
+    ws = torch.empty((splits * m * n,), dtype=torch.float32, device=x2.device) if splits > 1 else None
+    rc = lib.vpsa_packed_gemm(_p(x2), c_long(x2.stride(0)), _p(wp), _p(bias), _p(out), c_long(out.stride(0)),
+                              _p(ws), c_int(m), c_int(n), c_int(k), c_int(1 if pair else 0), c_int(splits),
+                              _stream())
+    return out if rc == 0 else None
+
+
 def _skinny_ok(x, w, bias):
     return (_skinny_enabled and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
             and w.is_contiguous() and x.dim() == 2 and 0 < x.shape[0] <= SKINNY_MAX_ROWS
@@ -359,15 +393,21 @@ def _skinny_ok(x, w, bias):
 #   down    4096x14336: the library wins at every batch (24.8 vs 25.6)  -> library
 # From ~24 rows on (40 rows: qkv 17 vs 20, gate_up 53 vs 52) the library GEMM is as good or better.
 SMALL_BATCH_ROWS = 16
+PACKED_MAX_ROWS = 64
 PAIR_STREAM_MAX_ROWS = 32
 DIRECT_MAX_WEIGHT_ELEMS = 4096 * 4096
 STREAM_MAX_K = 8192
 
 
-def linear(x, w, bias=None):
+def linear(x, w, bias=None, packed=None):
     """y = x @ w.T (+ bias).  Decode batches of up to 16 rows run the weight-streaming MFMA
     kernels of ``csrc/kernels/gemm.hip`` (which one depends on the weight's shape); everything
-    else goes to the library GEMM (hipBLASLt)."""
+    else goes to the library GEMM (hipBLASLt).  ``packed``: ``pack_weight(w)`` when the caller
+    keeps one (decode-only steps): up to 64 rows then stream that copy."""
+    if packed is not None and x.dim() == 2 and x.shape[0] <= PACKED_MAX_ROWS and _skinny_ok(x, w, bias):
+        y = packed_linear(x, packed, w.shape[0], w.shape[1], bias, False)
+        if y is not None:
+            return y
     if x.dim() == 2 and x.shape[0] <= SMALL_BATCH_ROWS and _skinny_ok(x, w, bias):
         y = None
         if w.numel() <= DIRECT_MAX_WEIGHT_ELEMS:
@@ -379,9 +419,13 @@ def linear(x, w, bias=None):
     return torch.nn.functional.linear(x, w, bias)
 
 
-def gate_up_silu(x, w_gate_up):
+def gate_up_silu(x, w_gate_up, packed=None):
     """silu(x @ Wg.T) * (x @ Wu.T) for ``w_gate_up = [Wg; Wu]``: fused in one kernel for
-    decode batches, library GEMM + activation kernel otherwise."""
+    decode batches, library GEMM + activation kernel otherwise.  ``packed`` as in ``linear``."""
+    if packed is not None and x.dim() == 2 and x.shape[0] <= PACKED_MAX_ROWS and _skinny_ok(x, w_gate_up, None):
+        y = packed_linear(x, packed, w_gate_up.shape[0], w_gate_up.shape[1], None, True)
+        if y is not None:
+            return y
     if x.dim() == 2 and x.shape[0] <= PAIR_STREAM_MAX_ROWS and _skinny_ok(x, w_gate_up, None):
         y = _stream_gemm(x, w_gate_up, None, True)
         if y is None and x.shape[0] <= 8:
