@@ -276,3 +276,29 @@ def test_n_choices_and_prompt_lists():
         assert [c["text"] for c in d["choices"]] == single
 
     run(_with_server(fn))
+
+
+def test_a_client_that_hangs_up_mid_stream_is_not_an_error(caplog):
+    """A peer closing the connection while tokens are streaming (a load generator at its time limit,
+    a router failing over) aborts the request in the engine and leaves no traceback in the log."""
+    import logging
+
+    async def fn(s, eng):
+        body = {"model": "tiny-llama", "prompt": "a b c", "max_tokens": 400, "temperature": 0,
+                "ignore_eos": True, "stream": True}
+        r = await s.post("/v1/completions", json=body)
+        await r.content.readline()               # generation has started
+        r.close()                                 # hang up without reading the rest
+        for _ in range(200):                      # the engine drops the request instead of finishing it
+            await asyncio.sleep(0.05)
+            if not eng.has_work():
+                break
+        assert not eng.has_work()
+        assert eng.scheduler.running == [] and not eng.scheduler.waiting
+        async with s.get("/health") as h:         # and keeps serving
+            assert h.status == 200
+
+    with caplog.at_level(logging.ERROR):
+        run(_with_server(fn))
+    assert not [rec for rec in caplog.records if "Error handling request" in rec.getMessage()
+                or rec.exc_info], [rec.getMessage() for rec in caplog.records]

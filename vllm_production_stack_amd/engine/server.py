@@ -595,12 +595,17 @@ class EngineServer:
                     usage["prompt_tokens_details"] = {"cached_tokens": tot["cached"]}
                 await send(chunk(usage=usage, choices=False))
             await send(b"data: [DONE]\n\n")
-        except (ConnectionResetError, asyncio.CancelledError):
+        except (ConnectionResetError, asyncio.CancelledError) as gone:
             for t in tasks:
-                t.cancel()
+                t.cancel()  # generate()'s finally aborts the engine requests
             self._end_span(span, t0, tot["t_first"], tot["n_out"], tot["cached"], tot["queue_time"], "abort",
                            error="client disconnected")
-            raise
+            if isinstance(gone, asyncio.CancelledError):
+                raise
+            # the peer hung up mid-stream (a load generator at its time limit, a router failing
+            # over): not an error of this server, and there is nobody left to answer
+            log.debug("client of %s disconnected after %d tokens", rid, tot["n_out"])
+            return resp
         except Exception as e:
             for t in tasks:
                 t.cancel()
