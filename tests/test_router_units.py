@@ -438,3 +438,50 @@ def test_pii_regex_api_keys_and_extra_patterns():
     assert not a.analyze("the task-force risk-management plan").has_pii
     assert a.analyze("zip 94103").types == {pii.PIIType.LOCATION}
     assert a.analyze("mail bob@example.com", types={pii.PIIType.PHONE}).has_pii is False
+
+
+def test_a_burst_of_new_conversations_lands_evenly_even_over_several_workers(monkeypatch):
+    """320 first turns at once through four router workers (each sees only its own in-flight
+    counts, all share one rotation position): every replica gets its share within a few users; follow-up
+    turns stay where their conversation is."""
+    import multiprocessing
+
+    from vllm_production_stack_amd.router import workers
+    from vllm_production_stack_amd.router.routing import PrefixAwareRouter
+    from vllm_production_stack_amd.router.stats import RequestStatsMonitor
+
+    class EP:
+        def __init__(self, url):
+            self.url = url
+
+    shared = multiprocessing.Value("Q", 0)
+    monkeypatch.setattr(workers, "shared_rr_counter", lambda: shared)
+    eps = [EP(f"http://10.0.0.{i}:8000") for i in range(8)]
+    system = "You are a helpful assistant. " * 150                        # shared by every user
+    trie = PrefixAwareRouter().hashtrie                                    # one trie, as with the shared service
+    fleet = []
+    for _ in range(4):
+        r = PrefixAwareRouter()
+        r.hashtrie = trie
+        fleet.append((r, RequestStatsMonitor(10.0)))
+    rng = __import__("random").Random(5)
+    placed = {}
+    sizes = [83, 71, 90, 76]                                              # what SO_REUSEPORT hashing might deal out
+    user = 0
+    for (router, mon), n in zip(fleet, sizes):
+        for _ in range(n):
+            prompt = system + f"user {user} " + " ".join(str(rng.random()) for _ in range(3000))
+            url = router.route_request(eps, {}, mon.get_request_stats(1.0), None, {"prompt": prompt})
+            mon.on_new_request(url, f"r{user}", 1.0)
+            placed[user] = (url, prompt)
+            user += 1
+    counts = {e.url: 0 for e in eps}
+    for url, _ in placed.values():
+        counts[url] += 1
+    assert sum(counts.values()) == 320 and max(counts.values()) - min(counts.values()) <= 3, counts
+    # round two: any worker routes a follow-up to the replica holding the conversation
+    for u in (0, 100, 200, 319):
+        url, prompt = placed[u]
+        router, mon = fleet[(u + 1) % 4]
+        assert router.route_request(eps, {}, mon.get_request_stats(2.0), None,
+                                    {"prompt": prompt + " answer. next question"}) == url

@@ -127,9 +127,13 @@ class PrefixAwareRouter(RoutingInterface):
 
     A match is honoured when it covers at least ``min_match_ratio`` of the prompt (a mere
     shared system prompt must not pin every conversation to one engine); among the
-    candidate endpoints the one with the fewest router-tracked in-flight requests wins, with
-    a random choice between equals.  ``min_match_ratio=0`` and no request statistics give
-    the reference behaviour: any match wins, random choice among the matched endpoints."""
+    candidate endpoints the one with the fewest router-tracked in-flight requests wins.  Equals
+    are taken in rotation, from a position shared by all router workers: a burst of new
+    conversations (every user of a benchmark round at once, spread over several workers that
+    each see only their own in-flight counts) lands evenly on the replicas instead of
+    binomially (320 users on 8 replicas: 40 each instead of 40 +- 6, and the slowest replica
+    sets the round time).  ``min_match_ratio=0`` and no request statistics give the reference
+    behaviour: any match wins among the matched endpoints."""
 
     def __init__(self, max_nodes: int = 4_000_000, min_match_ratio: float = 0.5):
         from . import workers
@@ -140,15 +144,34 @@ class PrefixAwareRouter(RoutingInterface):
         self.shared = workers.SharedTrieClient(path) if path else None
         self.hashtrie = None if self.shared else HashTrie(chunk_size=128, max_nodes=max_nodes)
         self.min_match_ratio = min_match_ratio
+        self._turn = workers.shared_rr_counter()  # one rotation for all router workers
+        self._local_turn = random.randrange(1 << 16)
 
-    @staticmethod
-    def _least_loaded(urls: list[str], request_stats) -> str:
+    def _next_turn(self) -> int:
+        if self._turn is not None:
+            with self._turn.get_lock():
+                n = self._turn.value
+                self._turn.value = n + 1
+            return n
+        self._local_turn += 1
+        return self._local_turn
+
+    def _least_loaded(self, urls: list[str], request_stats) -> str:
         def load(u):
             st = request_stats.get(u) if request_stats else None
             return 0 if st is None else st.in_prefill_requests + st.in_decoding_requests
 
         best = min(load(u) for u in urls)
-        return random.choice([u for u in urls if load(u) == best])
+        equals = [u for u in urls if load(u) == best]
+        if len(equals) == 1:
+            return equals[0]
+        # the first of the equals at or after the rotating position in the (sorted) candidate list
+        start = self._next_turn() % len(urls)
+        for k in range(len(urls)):
+            u = urls[(start + k) % len(urls)]
+            if u in equals:
+                return u
+        return equals[0]
 
     def _choose(self, prompt, available, matched_len, matched, request_stats) -> str:
         strong = matched and matched_len >= self.min_match_ratio * len(prompt)
