@@ -251,6 +251,44 @@ def test_speech_model_bf16_tracks_fp32_on_gpu():
     assert all(tok < cfg.eos_token_id for x in toks for tok in x)
 
 
+def test_speech_graph_decode_matches_the_eager_loop_on_gpu():
+    """Greedy decoding through the captured HIP graph (static K/V, device-side position) against
+    the eager loop: token-exact in fp32 for batch sizes that pad to different captured steps and
+    across a re-capture; in bf16 the same path runs the dense single-query attention kernel and
+    the weight-streaming projections."""
+    import numpy as np
+
+    from vllm_production_stack_amd import ops
+    from vllm_production_stack_amd.models import whisper as W
+
+    cfg, _ = W.resolve_whisper("openai/whisper-small")
+    dev = torch.device("cuda", 0)
+    m = W.WhisperModel(cfg, torch.float32, dev)
+    m.init_random(5)
+    assert m.use_graphs
+    rng = np.random.default_rng(0)
+    waves = torch.from_numpy((0.1 * rng.standard_normal((3, W.N_SAMPLES))).astype(np.float32))
+    prompts = [m.prompt_ids(None)] * 3
+    got3 = m.transcribe_windows(waves, prompts, max_new_tokens=24)
+    got1 = m.transcribe_windows(waves[:1], prompts[:1], max_new_tokens=24)
+    assert sorted(m._gstate["graphs"]) == [1, 4]
+    m.use_graphs = False
+    want3 = m.transcribe_windows(waves, prompts, max_new_tokens=24)
+    assert got3 == want3 and got1 == want3[:1]
+    m.use_graphs = True
+    m.drop_graphs()
+    assert m.transcribe_windows(waves, prompts, max_new_tokens=24) == want3
+    # bf16: the fused kernels are what the step runs
+    m16 = W.WhisperModel(cfg, torch.bfloat16, dev)
+    m16.w = {k: v.to(torch.bfloat16) for k, v in m.w.items()}
+    st = m16._graph_state()
+    q = torch.randn(3, cfg.d_model, device=dev).to(torch.bfloat16)
+    assert ops.dense_decode_attention_supported(q, st["ck"][0][:3], st["cv"][0][:3], cfg.decoder_heads)
+    toks = m16.transcribe_windows(waves, prompts, max_new_tokens=24)
+    assert len(toks) == 3 and all(0 < len(x) <= 24 for x in toks)
+    assert all(tok < cfg.eos_token_id for x in toks for tok in x)
+
+
 def test_opt_125m_serves_on_the_hip_kernels_and_other_head_sizes_on_the_generic_path():
     """OPT-125m (head_dim 64) runs the MFMA attention kernels with padded heads and HIP-graph
     decode; a head size the kernels do not cover (32) takes the PyTorch attention definitions,

@@ -351,6 +351,35 @@ def test_packed_gemm_matches_fp32(m, n, k, bias, pair):
     assert torch.equal(via, got)
 
 
+@pytest.mark.parametrize("b,heads,t,pos", [(1, 12, 1500, None), (3, 12, 448, 100), (5, 6, 448, 0),
+                                           (32, 20, 1500, None), (2, 16, 448, 447), (4, 8, 300, 256)])
+def test_dense_decode_attention_matches_fp32(b, heads, t, pos):
+    """Single-query attention over dense K/V (speech decoder: self-attention up to a position
+    read from device memory, cross-attention over all encoder positions) against fp32; the
+    query is a strided slice of a fused q/k/v row, V has a per-channel offset."""
+    torch.manual_seed(b * 7 + t)
+    d = heads * 64
+    qkv = torch.randn(b, 3 * d, device=DEV).to(BF)
+    q = qkv[:, :d]
+    k = torch.randn(b, t, d, device=DEV).to(BF)
+    v = (torch.randn(b, t, d, device=DEV) + torch.linspace(-2, 2, d, device=DEV)).to(BF)
+    pos_t = None if pos is None else torch.tensor([pos], dtype=torch.long, device=DEV)
+    assert ops.dense_decode_attention_supported(q, k, v, heads)
+    # poison what must not be read
+    n = t if pos is None else pos + 1
+    k[:, n:] = float("nan")
+    v[:, n:] = float("nan")
+    got = ops.dense_decode_attention(q, k, v, heads, pos_t).float()
+    qh = q.float().view(b, heads, 1, 64)
+    kh = k[:, :n].float().view(b, n, heads, 64).transpose(1, 2)
+    vh = v[:, :n].float().view(b, n, heads, 64).transpose(1, 2)
+    want = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, dim=-1) @ vh).transpose(1, 2).reshape(b, d)
+    err = ((got - want).abs().amax(dim=1) / want.abs().amax(dim=1)).max().item()
+    assert err < 1e-2, err
+    assert not ops.dense_decode_attention_supported(q.float(), k.float(), v.float(), heads)
+    assert not ops.dense_decode_attention_supported(q, k, v, heads + 1)
+
+
 def test_skinny_linear_strided_rows_and_fallback():
     torch.manual_seed(3)
     base = torch.randn(9, 2 * 4096, device=DEV).to(BF)

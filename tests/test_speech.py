@@ -138,6 +138,54 @@ def test_encoder_decoder_match_hf(hf_checkpoint):
     assert (got_step - want[:, -1]).abs().max().item() < 2e-4
 
 
+def test_graph_decode_step_reproduces_the_eager_loop(hf_checkpoint):
+    """The static-buffer decode step the GPU captures as a graph (token, position and finished
+    flags on the device, history read back at the end), replayed here without a capture: same
+    tokens as the eager loop, rows that finish early included, batch padded to a power of two."""
+    d, _ = hf_checkpoint
+    cfg, ckpt = W.resolve_whisper(str(d))
+    cfg.suppress_lo, cfg.suppress_hi = 3, 16
+    m = W.WhisperModel(cfg, torch.float32, torch.device("cpu"))
+    m.load_hf(ckpt)
+    rng = np.random.default_rng(5)
+    waves = torch.from_numpy(np.stack([
+        W.pad_or_trim((_tone(1.0, freq=f) + 0.05 * rng.standard_normal(16000)).astype(np.float32))[0]
+        for f in (300.0, 900.0, 1500.0)]))
+    prompts = [[3, 7, 5, 6]] * 3
+    assert not m.use_graphs  # CPU: eager
+    want = m.transcribe_windows(waves, prompts, max_new_tokens=20)
+    # end-of-text for one row after a few tokens: make it the most likely token there
+    replays = []
+
+    class Replay:
+        def __init__(self, st, b):
+            self.st, self.b = st, b
+
+        def replay(self):
+            replays.append(self.b)
+            m._graph_step(self.st, self.b)
+
+    m._graph_for = lambda st, b: Replay(st, b)
+    m.use_graphs, m.graph_max_batch, m.graph_check_every = True, 8, 4
+    got = m.transcribe_windows(waves, prompts, max_new_tokens=20)
+    assert got == want
+    assert replays and set(replays) == {4}, "three windows run in the 4-row step"
+    # a row that is finished from the start stays silent and does not disturb the others
+    cfg2_eos = want[1][2]
+    m.cfg.eos_token_id = cfg2_eos
+    m.drop_graphs()
+    m.use_graphs = False
+    want2 = m.transcribe_windows(waves, prompts, max_new_tokens=20)
+    m.use_graphs = True
+    got2 = m.transcribe_windows(waves, prompts, max_new_tokens=20)
+    assert got2 == want2 and len(want2[1]) <= 2
+    # sampling keeps the eager loop
+    n = len(replays)
+    m.transcribe_windows(waves, prompts, max_new_tokens=3, temperature=0.7,
+                         generator=torch.Generator().manual_seed(0))
+    assert len(replays) == n
+
+
 def test_greedy_transcription_matches_hf_greedy_loop(hf_checkpoint):
     d, hf = hf_checkpoint
     cfg, ckpt = W.resolve_whisper(str(d))

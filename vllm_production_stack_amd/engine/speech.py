@@ -97,6 +97,9 @@ class SpeechEngine:
         self.metrics = EngineMetrics(cfg.model_name)
         self.max_model_len = self.model_cfg.max_target_positions
         self.max_batch = max(1, min(cfg.max_num_seqs, 32))
+        self.model.graph_max_batch = self.max_batch
+        if cfg.enforce_eager:
+            self.model.use_graphs = False
         self._q: "queue.Queue[_Window | None]" = queue.Queue()
         self._pending = 0
         self._lock = threading.Lock()
@@ -193,6 +196,7 @@ class SpeechEngine:
             return 0
         freed = self.model.weight_bytes() if self.device.type == "cuda" else 0
         if self.device.type == "cuda":
+            self.model.drop_graphs()  # captured steps hold the weights' addresses
             self._host_weights = {k: v.to("cpu") for k, v in self.model.w.items()} if level == 1 else None
             self.model.w = {}
             torch.cuda.empty_cache()

@@ -12,6 +12,12 @@ against a cross-attention K/V that is computed once per window.  Everything is d
 the matmuls go to the library GEMM.  Attention is written out as two batched GEMMs and a
 softmax so that no hidden JIT kernel is involved.
 
+On a GPU the greedy decode loop is a captured HIP graph: one replay per token over static
+self-/cross-attention K/V buffers, the position and the running token kept on the device, and
+the host looking at the end-of-text flags only every few steps.  An eager decode step of a
+12-layer model is about 400 launches of a few microseconds of work each; the replay removes the
+launch gaps and the per-token device-to-host round trip.
+
 Weights follow the Hugging Face layout (``model.encoder.*`` / ``model.decoder.*``) when a
 checkpoint directory is given; otherwise they are drawn from a seeded generator.
 """
@@ -26,6 +32,8 @@ from pathlib import Path
 import numpy as np
 import torch
 import torch.nn.functional as F
+
+from .. import ops
 
 SAMPLE_RATE = 16000
 N_FFT = 400
@@ -203,17 +211,21 @@ def _sinusoids(length: int, channels: int) -> torch.Tensor:
 # ---------------------------------------------------------------------------- model
 def _attend(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
             mask: torch.Tensor | None = None) -> torch.Tensor:
-    """q [B, Tq, d], k/v [B, Tk, d] -> [B, Tq, d]; scores in fp32."""
+    """q [B, Tq, d], k/v [B, Tk, d] -> [B, Tq, d].  The score matrix makes three trips through
+    memory in the model's dtype (GEMM out, softmax in and out, GEMM in); the softmax accumulates
+    in fp32 internally.  The 1/sqrt(head) factor (a power of two for 64-channel heads, so exact)
+    goes onto q.  An fp32 copy of the scores - 3.4 GB per layer for 32 windows of Whisper-small -
+    would add nothing: the GEMM has already rounded them to the model's dtype."""
     b, tq, d = q.shape
     tk = k.shape[1]
     hd = d // heads
-    qh = q.view(b, tq, heads, hd).transpose(1, 2)
+    qh = (q * (hd ** -0.5)).view(b, tq, heads, hd).transpose(1, 2)
     kh = k.view(b, tk, heads, hd).transpose(1, 2)
     vh = v.view(b, tk, heads, hd).transpose(1, 2)
-    s = torch.matmul(qh, kh.transpose(-1, -2)).float() * (hd ** -0.5)
+    s = torch.matmul(qh, kh.transpose(-1, -2))
     if mask is not None:
-        s = s + mask
-    p = torch.softmax(s, dim=-1).to(q.dtype)
+        s = s + mask.to(s.dtype)
+    p = torch.softmax(s, dim=-1)
     return torch.matmul(p, vh).transpose(1, 2).reshape(b, tq, d)
 
 
@@ -224,6 +236,12 @@ class WhisperModel:
         self.device = device
         self.w: dict[str, torch.Tensor] = {}
         self.filters = torch.from_numpy(mel_filterbank(cfg.num_mel_bins)).to(device)
+        # graph decode (GPU only): static buffers for ``graph_max_batch`` windows, one captured
+        # step per power-of-two batch size
+        self.use_graphs = device.type == "cuda"
+        self.graph_max_batch = 32
+        self.graph_check_every = 8
+        self._gstate: dict | None = None
 
     # ------------------------------------------------------------------ weights
     def _names(self) -> dict[str, tuple[int, ...]]:
@@ -375,6 +393,149 @@ class WhisperModel:
         x = self._ln(x[:, -1], "decoder.layer_norm")
         return F.linear(x, w["decoder.embed_tokens.weight"]).float()
 
+    # ------------------------------------------------------------------ graph decode
+    def drop_graphs(self) -> None:
+        """Forget the captured steps and their buffers (before the weights move or are freed)."""
+        self._gstate = None
+
+    def _suppress_mask(self) -> torch.Tensor:
+        c = self.cfg
+        ids = torch.arange(c.vocab_size, device=self.device)
+        lo = c.suppress_lo or c.eos_token_id + 1
+        hi = c.suppress_hi or c.vocab_size
+        return (ids >= lo) & (ids < hi) & (ids != c.eos_token_id)
+
+    def _graph_state(self) -> dict:
+        """Static device state of the graph decode path, allocated on first use: the running
+        token / position / finished flags, the emitted-token history, self-attention K/V for
+        every target position and cross-attention K/V, all for ``graph_max_batch`` windows
+        (whisper-large at 32 windows: 2.3 GB + 7.9 GB), and q/k/v weights fused per layer."""
+        if self._gstate is not None:
+            return self._gstate
+        c, w, dev = self.cfg, self.w, self.device
+        nb, t, s, d = self.graph_max_batch, c.max_target_positions, c.max_source_positions, c.d_model
+
+        def z(*shape):
+            return torch.zeros(shape, dtype=self.dtype, device=dev)
+
+        wqkv, bqkv = [], []
+        for i in range(c.decoder_layers):
+            p = f"decoder.layers.{i}.self_attn"
+            wqkv.append(torch.cat([w[p + ".q_proj.weight"], w[p + ".k_proj.weight"], w[p + ".v_proj.weight"]]))
+            bqkv.append(torch.cat([w[p + ".q_proj.bias"], torch.zeros_like(w[p + ".q_proj.bias"]),
+                                   w[p + ".v_proj.bias"]]))
+        layers = range(c.decoder_layers)
+        self._gstate = {
+            "tok": torch.zeros(nb, dtype=torch.long, device=dev),
+            "pos": torch.zeros(1, dtype=torch.long, device=dev),
+            "done": torch.ones(nb, dtype=torch.bool, device=dev),
+            "hist": torch.full((nb, t), c.eos_token_id, dtype=torch.long, device=dev),
+            "kc": [z(nb, t, d) for _ in layers], "vc": [z(nb, t, d) for _ in layers],
+            "ck": [z(nb, s, d) for _ in layers], "cv": [z(nb, s, d) for _ in layers],
+            "steps": torch.arange(t, device=dev), "suppress": self._suppress_mask(),
+            "wqkv": wqkv, "bqkv": bqkv, "graphs": {}, "pool": None,
+        }
+        return self._gstate
+
+    def _attend1(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torch.Tensor | None,
+                 mask: torch.Tensor | None) -> torch.Tensor:
+        """One query per row: q [B, d] against k / v [B, T, d] -> [B, d].  bf16 on the GPU with
+        64-channel heads (every published Whisper size) runs the fused dense single-query kernel
+        (``csrc/kernels/dense_attention.hip``); anything else the batched-GEMM definition."""
+        heads = self.cfg.decoder_heads
+        if ops.dense_decode_attention_supported(q, k, v, heads):
+            return ops.dense_decode_attention(q, k, v, heads, pos)
+        return _attend(q[:, None], k, v, heads, mask)[:, 0]
+
+    def _graph_step(self, st: dict, b: int) -> None:
+        """One greedy decoder step for rows [0, b) of the static state: consumes ``tok`` at
+        ``pos``, appends its K/V, writes the next token to ``tok`` and ``hist[:, pos]`` and
+        advances ``pos``.  Finished rows keep emitting end-of-text.  Projections of up to 16
+        rows take the weight-streaming kernels of ``ops.linear``."""
+        c, w = self.cfg, self.w
+        d, eos = c.d_model, c.eos_token_id
+        tok, pos, done = st["tok"][:b], st["pos"], st["done"][:b]
+
+        def lin(x, prefix):
+            return ops.linear(x, w[prefix + ".weight"], w.get(prefix + ".bias"))
+
+        x = F.embedding(tok, w["decoder.embed_tokens.weight"]) + \
+            w["decoder.embed_positions.weight"].index_select(0, pos)
+        mask = torch.where(st["steps"] <= pos, 0.0, float("-inf"))  # keys beyond pos are not written yet
+        for i in range(c.decoder_layers):
+            p = f"decoder.layers.{i}"
+            h = self._ln(x, p + ".self_attn_layer_norm")
+            qkv = ops.linear(h, st["wqkv"][i], st["bqkv"][i])
+            kc, vc = st["kc"][i][:b], st["vc"][i][:b]
+            kc.index_copy_(1, pos, qkv[:, None, d:2 * d])
+            vc.index_copy_(1, pos, qkv[:, None, 2 * d:])
+            x = x + lin(self._attend1(qkv[:, :d], kc, vc, pos, mask), p + ".self_attn.out_proj")
+            h = self._ln(x, p + ".encoder_attn_layer_norm")
+            a = self._attend1(lin(h, p + ".encoder_attn.q_proj"), st["ck"][i][:b], st["cv"][i][:b], None, None)
+            x = x + lin(a, p + ".encoder_attn.out_proj")
+            h = self._ln(x, p + ".final_layer_norm")
+            x = x + lin(F.gelu(lin(h, p + ".fc1")), p + ".fc2")
+        logits = ops.linear(self._ln(x, "decoder.layer_norm"), w["decoder.embed_tokens.weight"]).float()
+        logits.masked_fill_(st["suppress"], float("-inf"))
+        nxt = torch.where(done, eos, logits.argmax(dim=-1))
+        done.logical_or_(nxt == eos)
+        st["hist"][:b].index_copy_(1, pos, nxt[:, None])
+        tok.copy_(nxt)
+        pos.add_(1)
+
+    def _graph_for(self, st: dict, b: int) -> "torch.cuda.CUDAGraph":
+        """The captured step for batch size ``b``; captured (after one eager run that lets the
+        libraries load their kernels) on first use.  Leaves the row state dirty."""
+        g = st["graphs"].get(b)
+        if g is None:
+            st["pos"].zero_()
+            cur = torch.cuda.current_stream(self.device)
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self._graph_step(st, b)
+            cur.wait_stream(side)
+            st["pos"].zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=st["pool"]):
+                self._graph_step(st, b)
+            if st["pool"] is None:
+                st["pool"] = g.pool()
+            st["graphs"][b] = g
+        return g
+
+    def _generate_graph(self, cross: list, tokens: torch.Tensor, steps: int) -> list[list[int]]:
+        """Greedy decoding with one graph replay per token.  The prompt runs eagerly (several
+        positions at once); its K/V and the cross K/V are copied into the static buffers."""
+        c = self.cfg
+        b, n0 = tokens.shape
+        eos = c.eos_token_id
+        nb = min(1 << (b - 1).bit_length(), self.graph_max_batch)
+        st = self._graph_state()
+        g = self._graph_for(st, nb)
+        cache: list = [None] * c.decoder_layers
+        logits = self.decode(tokens, 0, cross, cache)
+        logits[:, st["suppress"]] = float("-inf")
+        first = logits.argmax(dim=-1)
+        st["tok"][:b] = first
+        st["pos"].fill_(n0)
+        st["done"][:nb] = True
+        st["done"][:b] = first == eos
+        st["hist"][:nb].fill_(eos)
+        for i in range(c.decoder_layers):
+            st["kc"][i][:b, :n0] = cache[i][0]
+            st["vc"][i][:b, :n0] = cache[i][1]
+            st["ck"][i][:b] = cross[i][0]
+            st["cv"][i][:b] = cross[i][1]
+        ran = 0
+        for _ in range(steps - 1):
+            g.replay()
+            ran += 1
+            if ran % self.graph_check_every == 0 and bool(st["done"][:b].all()):
+                break
+        rows = torch.cat([first[:, None], st["hist"][:b, n0:n0 + ran]], dim=1).tolist()
+        return [row[:row.index(eos)] if eos in row else row for row in rows]
+
     # ------------------------------------------------------------------ generation
     def prompt_ids(self, language_token: int | None, task: str = "transcribe") -> list[int]:
         c = self.cfg
@@ -393,17 +554,16 @@ class WhisperModel:
         b = windows.shape[0]
         mel = log_mel(windows.to(self.device), c.num_mel_bins, self.filters)
         cross = self.cross_kv(self.encode(mel))
-        cache: list = [None] * c.decoder_layers
         tokens = torch.tensor(prompts, dtype=torch.long, device=self.device)
         limit = c.max_target_positions - tokens.shape[1]
         steps = limit if max_new_tokens is None else min(limit, max_new_tokens)
+        if self.use_graphs and temperature <= 0 and b <= self.graph_max_batch and steps > 0:
+            return self._generate_graph(cross, tokens, steps)
+        cache: list = [None] * c.decoder_layers
         done = torch.zeros(b, dtype=torch.bool, device=self.device)
         out: list[list[int]] = [[] for _ in range(b)]
         offset, feed = 0, tokens
-        ids = torch.arange(c.vocab_size, device=self.device)
-        lo = c.suppress_lo or c.eos_token_id + 1
-        hi = c.suppress_hi or c.vocab_size
-        suppress = (ids >= lo) & (ids < hi) & (ids != c.eos_token_id)
+        suppress = self._suppress_mask()
         for step in range(steps):
             logits = self.decode(feed, offset, cross, cache)
             offset += feed.shape[1]

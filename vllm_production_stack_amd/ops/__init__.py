@@ -35,7 +35,7 @@ def _kernels():
             "vpsa_skinny_gemm", "vpsa_hbm_read_probe", "vpsa_set_gemm_variant", "vpsa_stream_gemm",
             "vpsa_stream_gemm_splits", "vpsa_set_stream_targets", "vpsa_rans_encode", "vpsa_rans_pack",
             "vpsa_rans_decode", "vpsa_sample", "vpsa_grouped_gemm", "vpsa_packed_gemm",
-            "vpsa_packed_gemm_splits", "vpsa_set_packed_target",
+            "vpsa_packed_gemm_splits", "vpsa_set_packed_target", "vpsa_dense_decode_attention",
         ):
             getattr(lib, name).restype = c_int
         if os.environ.get("VPSA_PREFILL_VARIANT"):  # pin one prefill kernel for A/B runs
@@ -268,6 +268,32 @@ def paged_prefill(q, out, pool, layer, block_tables, cu_q, ctx_lens, tile_seq, t
         c_int(tile_seq.numel()), c_int(ctx_lens.numel()), c_int(tile_rows), c_int(n_q), c_int(n_kv),
         c_float(scale), _stream())
     _check(rc, "paged_prefill")
+
+
+def dense_decode_attention_supported(q, k, v, heads: int) -> bool:
+    """Shapes the dense single-query kernel covers: bf16 on the GPU, 64-channel heads, unit
+    stride over channels, 16-byte aligned rows."""
+    d = q.shape[-1]
+    if not all(t.is_cuda and t.dtype == torch.bfloat16 for t in (q, k, v)):
+        return False
+    return (d == heads * 64 and q.dim() == 2 and k.dim() == 3
+            and k.shape == v.shape and k.stride() == v.stride() and k.shape[0] == q.shape[0] and k.shape[2] == d
+            and q.stride(1) == 1 and k.stride(2) == 1 and q.stride(0) % 8 == 0 and k.stride(0) % 8 == 0
+            and k.stride(1) % 8 == 0 and (q.data_ptr() | k.data_ptr() | v.data_ptr()) % 16 == 0)
+
+
+def dense_decode_attention(q, k, v, heads: int, pos=None, out=None):
+    """softmax(q k^T / 8) v for ONE query per batch row over dense K/V: q [B, heads * 64],
+    k / v [B, T, heads * 64] -> [B, heads * 64].  ``pos`` (one int64 on the device) limits the
+    keys to positions 0..pos; None attends to all T.  Graph-capturable."""
+    b, d = q.shape
+    if out is None:
+        out = torch.empty((b, d), dtype=q.dtype, device=q.device)
+    rc = _kernels().vpsa_dense_decode_attention(
+        _p(q), c_long(q.stride(0)), _p(k), _p(v), c_long(k.stride(0)), c_long(k.stride(1)), _p(pos),
+        c_int(b), c_int(heads), c_int(k.shape[1]), _p(out), c_long(out.stride(0)), c_float(0.125), _stream())
+    _check(rc, "dense_decode_attention")
+    return out
 
 
 def decode_num_splits(num_seqs: int, n_kv: int, max_ctx: int) -> int:
