@@ -380,6 +380,31 @@ def test_dense_decode_attention_matches_fp32(b, heads, t, pos):
     assert not ops.dense_decode_attention_supported(q, k, v, heads + 1)
 
 
+@pytest.mark.parametrize("b,heads,tq,tk", [(2, 12, 1500, 1500), (1, 6, 100, 1500), (3, 20, 257, 333),
+                                           (2, 8, 4, 1500), (1, 12, 128, 64), (2, 16, 129, 1)])
+def test_dense_attention_matches_fp32(b, heads, tq, tk):
+    """Bidirectional MFMA flash attention over dense Q/K/V (speech encoder shapes, ragged tails
+    on both sides, strided views of a fused projection) against fp32; V has a per-channel offset
+    and every key a different weight, so a misplaced key or channel shows."""
+    torch.manual_seed(b * 13 + tq + tk)
+    d = heads * 64
+    qkv = torch.randn(b, tq, 3 * d, device=DEV).to(BF)
+    q = qkv[:, :, d:2 * d]
+    kv = torch.randn(b, tk, 2 * d, device=DEV)
+    kv[:, :, d:] += torch.linspace(-2, 2, d, device=DEV)
+    kv = kv.to(BF)
+    k, v = kv[:, :, :d], kv[:, :, d:]
+    assert ops.dense_attention_supported(q, k, v, heads)
+    got = ops.dense_attention(q, k, v, heads).float()
+    qh = q.float().view(b, tq, heads, 64).transpose(1, 2)
+    kh = k.float().view(b, tk, heads, 64).transpose(1, 2)
+    vh = v.float().view(b, tk, heads, 64).transpose(1, 2)
+    want = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, dim=-1) @ vh).transpose(1, 2).reshape(b, tq, d)
+    err = ((got - want).abs().amax(dim=-1) / want.abs().amax(dim=-1)).max().item()
+    assert err < 1.5e-2, err
+    assert not ops.dense_attention_supported(q.float(), k.float(), v.float(), heads)
+
+
 def test_skinny_linear_strided_rows_and_fallback():
     torch.manual_seed(3)
     base = torch.randn(9, 2 * 4096, device=DEV).to(BF)

@@ -211,7 +211,9 @@ def _sinusoids(length: int, channels: int) -> torch.Tensor:
 # ---------------------------------------------------------------------------- model
 def _attend(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
             mask: torch.Tensor | None = None) -> torch.Tensor:
-    """q [B, Tq, d], k/v [B, Tk, d] -> [B, Tq, d].  The score matrix makes three trips through
+    """q [B, Tq, d], k/v [B, Tk, d] -> [B, Tq, d].  Unmasked attention of 64-channel heads in bf16
+    on the GPU (the whole encoder, and the decoder prompt's cross-attention) runs the fused kernel of
+    ``csrc/kernels/dense_attention.hip``.  Otherwise: the score matrix makes three trips through
     memory in the model's dtype (GEMM out, softmax in and out, GEMM in); the softmax accumulates
     in fp32 internally.  The 1/sqrt(head) factor (a power of two for 64-channel heads, so exact)
     goes onto q.  An fp32 copy of the scores - 3.4 GB per layer for 32 windows of Whisper-small -
@@ -219,6 +221,8 @@ def _attend(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
     b, tq, d = q.shape
     tk = k.shape[1]
     hd = d // heads
+    if mask is None and hd == 64 and ops.dense_attention_supported(q, k, v, heads):
+        return ops.dense_attention(q, k, v, heads)  # bf16 on the GPU: MFMA flash kernel
     qh = (q * (hd ** -0.5)).view(b, tq, heads, hd).transpose(1, 2)
     kh = k.view(b, tk, heads, hd).transpose(1, 2)
     vh = v.view(b, tk, heads, hd).transpose(1, 2)

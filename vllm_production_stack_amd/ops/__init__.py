@@ -35,7 +35,7 @@ def _kernels():
             "vpsa_skinny_gemm", "vpsa_hbm_read_probe", "vpsa_set_gemm_variant", "vpsa_stream_gemm",
             "vpsa_stream_gemm_splits", "vpsa_set_stream_targets", "vpsa_rans_encode", "vpsa_rans_pack",
             "vpsa_rans_decode", "vpsa_sample", "vpsa_grouped_gemm", "vpsa_packed_gemm",
-            "vpsa_packed_gemm_splits", "vpsa_set_packed_target", "vpsa_dense_decode_attention",
+            "vpsa_packed_gemm_splits", "vpsa_set_packed_target", "vpsa_dense_decode_attention", "vpsa_dense_attention",
         ):
             getattr(lib, name).restype = c_int
         if os.environ.get("VPSA_PREFILL_VARIANT"):  # pin one prefill kernel for A/B runs
@@ -293,6 +293,32 @@ def dense_decode_attention(q, k, v, heads: int, pos=None, out=None):
         _p(q), c_long(q.stride(0)), _p(k), _p(v), c_long(k.stride(0)), c_long(k.stride(1)), _p(pos),
         c_int(b), c_int(heads), c_int(k.shape[1]), _p(out), c_long(out.stride(0)), c_float(0.125), _stream())
     _check(rc, "dense_decode_attention")
+    return out
+
+
+def dense_attention_supported(q, k, v, heads: int) -> bool:
+    """Shapes the dense bidirectional kernel covers: bf16 on the GPU, [B, T, heads * 64] with unit
+    stride over channels and 16-byte aligned rows."""
+    if not all(t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 3 for t in (q, k, v)):
+        return False
+    d = q.shape[-1]
+    return (d == heads * 64 and k.shape == v.shape and k.stride() == v.stride() and k.shape[0] == q.shape[0]
+            and k.shape[2] == d and k.shape[1] > 0 and q.stride(2) == 1 and k.stride(2) == 1
+            and all(x % 8 == 0 for x in (q.stride(0), q.stride(1), k.stride(0), k.stride(1)))
+            and (q.data_ptr() | k.data_ptr() | v.data_ptr()) % 16 == 0)
+
+
+def dense_attention(q, k, v, heads: int, out=None):
+    """softmax(q k^T / 8) v with every query attending to every key: q [B, Tq, heads * 64],
+    k / v [B, Tk, heads * 64] -> [B, Tq, heads * 64] (MFMA flash kernel, scores never stored)."""
+    b, tq, d = q.shape
+    if out is None:
+        out = torch.empty((b, tq, d), dtype=q.dtype, device=q.device)
+    rc = _kernels().vpsa_dense_attention(
+        _p(q), c_long(q.stride(0)), c_long(q.stride(1)), _p(k), _p(v), c_long(k.stride(0)), c_long(k.stride(1)),
+        _p(out), c_long(out.stride(0)), c_long(out.stride(1)), c_int(b), c_int(heads), c_int(tq),
+        c_int(k.shape[1]), c_float(0.125), _stream())
+    _check(rc, "dense_attention")
     return out
 
 
