@@ -85,6 +85,9 @@ def parse() -> argparse.Namespace:
                     help="cap the HBM KV pool (pages of 64 tokens) to exercise the host tier; 0 = size from HBM")
     ap.add_argument("--prefill-step-ms", type=float, default=30.0,
                     help="engine's latency-aware prefill admission target (0 = token budget only)")
+    ap.add_argument("--packed-decode-weights", default="", choices=["", "auto", "on", "off"],
+                    help="second copy of the MLP weights in matrix-core tile order for decode steps "
+                         "(empty = the engine's default)")
     ap.add_argument("--reference-rounds", type=int, default=3,
                     help="rounds of the second phase in the reference's own configuration (0 = skip)")
     ap.add_argument("--reference-users-per-gpu", type=int, default=15)
@@ -469,7 +472,9 @@ async def rank_main(a: argparse.Namespace) -> None:
             a, ctx, port0=a.base_port, routing=a.routing_logic, users_per_gpu=a.users_per_gpu,
             warm_users_per_gpu=a.warmup_users_per_gpu, rounds=a.steps, warm_rounds=a.warmup, user_base=0,
             engine_kwargs=dict(max_num_batched_tokens=a.max_num_batched_tokens, enable_prefix_caching=True,
-                               enable_chunked_prefill=True, kv_offload=off, prefill_step_ms=a.prefill_step_ms))
+                               enable_chunked_prefill=True, kv_offload=off, prefill_step_ms=a.prefill_step_ms,
+                               **({"packed_decode_weights": a.packed_decode_weights}
+                                  if a.packed_decode_weights else {})))
         ref = None
         if a.reference_rounds > 0:
             release_gpu_memory()
