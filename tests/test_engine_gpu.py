@@ -277,6 +277,8 @@ def test_speech_graph_decode_matches_the_eager_loop_on_gpu():
     assert got3 == want3 and got1 == want3[:1]
     m.use_graphs = True
     m.drop_graphs()
+    m.graph_max_batch = 4
+    assert m.capture_graphs() == 3  # what a replica does at start: batch sizes 1, 2, 4
     assert m.transcribe_windows(waves, prompts, max_new_tokens=24) == want3
     # bf16: the fused kernels are what the step runs
     m16 = W.WhisperModel(cfg, torch.bfloat16, dev)

@@ -113,6 +113,15 @@ class SpeechEngine:
     def _loop(self) -> None:
         if self.device.type == "cuda":
             torch.cuda.set_device(self.device)  # per-thread setting; a new thread starts on GPU 0
+            try:
+                t0 = time.time()
+                n = self.model.capture_graphs()
+                if n:
+                    log.info("decode step captured for %d batch sizes in %.1f s", n, time.time() - t0)
+            except Exception:  # noqa: BLE001 - the eager loop serves
+                log.exception("graph capture failed; decoding eagerly")
+                self.model.use_graphs = False
+                self.model.drop_graphs()
         while True:
             first = self._q.get()
             if first is None:

@@ -531,6 +531,21 @@ class WhisperModel:
             st["graphs"][b] = g
         return g
 
+    @torch.inference_mode()
+    def capture_graphs(self) -> int:
+        """Capture the decode step for every batch bucket now (replica start) instead of on the
+        first request that needs it; returns the number of graphs held."""
+        if not self.use_graphs:
+            return 0
+        st = self._graph_state()
+        b = 1
+        while True:
+            self._graph_for(st, min(b, self.graph_max_batch))
+            if b >= self.graph_max_batch:
+                break
+            b *= 2
+        return len(st["graphs"])
+
     def _generate_graph(self, cross: list, tokens: torch.Tensor, steps: int) -> list[list[int]]:
         """Greedy decoding with one graph replay per token.  The prompt runs eagerly (several
         positions at once); its K/V and the cross K/V are copied into the static buffers."""
