@@ -1029,7 +1029,8 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
     const uint16_t* __restrict__ cache, long page_stride, long v_offset,
     const int* __restrict__ block_tables, int max_blocks, const int* __restrict__ cu_q,
     const int* __restrict__ ctx_lens, const int* __restrict__ tile_seq,
-    const int* __restrict__ tile_q0, int n_q, int n_kv, float scale_log2e) {
+    const int* __restrict__ tile_q0, int n_q, int n_kv, float scale_log2e,
+    const float* __restrict__ rope) {
   extern __shared__ __attribute__((aligned(16))) char lds[];  // 3 x (16 KiB K + 16 KiB V)
 
   const int tid = threadIdx.x;
@@ -1076,11 +1077,37 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
   for (int rb = 0; rb < 2; ++rb) {
     const uint16_t* qp =
         q + (long)(row0 + (row_ok[rb] ? my_row[rb] : 0)) * q_stride + head * HEAD_DIM + 8 * h;
+    u32x4 qv[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      u32x4 v = *reinterpret_cast<const u32x4*>(qp + 16 * ks);
-      if (!row_ok[rb]) v = (u32x4){0, 0, 0, 0};
-      qf[rb][ks] = __builtin_bit_cast(bf16x8, v);
+      qv[ks] = *reinterpret_cast<const u32x4*>(qp + 16 * ks);
+      if (!row_ok[rb]) qv[ks] = (u32x4){0, 0, 0, 0};
+    }
+    if (rope != nullptr) {
+      // rotary embedding of the query row, here instead of in a pass of its own over the
+      // activations: channel c < 64 pairs with c + 64, which the same lane holds (fragment ks
+      // and ks + 4); table row = [cos(0..63), sin(0..63)] of the row's position
+      const float* cs = rope + (long)my_pos[rb] * HEAD_DIM + 8 * h;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs + 16 * ks);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(cs + 16 * ks + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(cs + 64 + 16 * ks);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(cs + 64 + 16 * ks + 4);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float ca = w < 2 ? c0[2 * w] : c1[2 * w - 4], cb = w < 2 ? c0[2 * w + 1] : c1[2 * w - 3];
+          const float sa = w < 2 ? s0[2 * w] : s1[2 * w - 4], sb = w < 2 ? s0[2 * w + 1] : s1[2 * w - 3];
+          const uint32_t lo = qv[ks][w], hi = qv[ks + 4][w];
+          const float x0 = bf16lo(lo), x1 = bf16hi(lo), y0 = bf16lo(hi), y1 = bf16hi(hi);
+          qv[ks][w] = pack_bf16x2(x0 * ca - y0 * sa, x1 * cb - y1 * sb);
+          qv[ks + 4][w] = pack_bf16x2(y0 * ca + x0 * sa, y1 * cb + x1 * sb);
+        }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      qf[rb][ks] = __builtin_bit_cast(bf16x8, qv[ks]);
       asm volatile("" : "+a"(qf[rb][ks]));  // an AGPR value from here on
     }
   }
@@ -1510,13 +1537,25 @@ VPSA_EXPORT int vpsa_prefill_tile_rows(int n_q, int n_kv, int want64) {
   return 32 * (4 / GP);
 }
 
-VPSA_EXPORT int vpsa_paged_prefill(const void* q, long q_stride, void* out, long out_stride,
-                                   const void* cache, long page_stride, long v_offset,
-                                   const int* block_tables, int max_blocks, const int* cu_q,
-                                   const int* ctx_lens, const int* tile_seq, const int* tile_q0,
-                                   int num_tiles, int num_seqs, int tile_rows, int n_q, int n_kv,
-                                   float scale, hipStream_t stream) {
+// 1 when the kernel that vpsa_paged_prefill would pick for this head layout and tile height can
+// apply the rotary embedding to its query rows itself (vpsa_paged_prefill_rope).
+VPSA_EXPORT int vpsa_prefill_fuses_rope(int n_q, int n_kv, int tile_rows) {
+  if (n_kv <= 0 || n_q % n_kv != 0) return 0;
+  const int v = g_prefill_variant;
+  return tile_rows == 64 && (n_q / n_kv) % 4 == 0 && (v < 0 || v >= 8);
+}
+
+// rope: null = q is already rotated; else the [position][HEAD_DIM] fp32 table (cos of the 64
+// channel pairs, then sin), and q holds UNROTATED rows at consecutive positions ending at each
+// sequence's context length.  Only the fourth-generation kernels take it (-4 otherwise).
+VPSA_EXPORT int vpsa_paged_prefill_rope(const void* q, long q_stride, void* out, long out_stride,
+                                        const void* cache, long page_stride, long v_offset,
+                                        const int* block_tables, int max_blocks, const int* cu_q,
+                                        const int* ctx_lens, const int* tile_seq, const int* tile_q0,
+                                        int num_tiles, int num_seqs, int tile_rows, int n_q, int n_kv,
+                                        float scale, const float* rope, hipStream_t stream) {
   if (num_tiles <= 0) return 0;
+  if (rope != nullptr && !vpsa_prefill_fuses_rope(n_q, n_kv, tile_rows)) return -4;
   if (n_q % n_kv != 0) return -1;
   const int G = n_q / n_kv;
   if (G == 3) return -1;  // the tile is 4 waves = GP heads x (4 / GP) row blocks: GP must divide 4
@@ -1547,10 +1586,10 @@ VPSA_EXPORT int vpsa_paged_prefill(const void* q, long q_stride, void* out, long
     if (variant < 0) variant = many_tiles ? 9 : 8;
     if (variant == 9) {
       hipLaunchKernelGGL((paged_prefill_kernel_v4<true>), grid, block, 98304, stream,
-                         VPSA_PREFILL_ARGS);
+                         VPSA_PREFILL_ARGS, rope);
     } else if (variant == 8) {
       hipLaunchKernelGGL((paged_prefill_kernel_v4<false>), grid, block, 98304, stream,
-                         VPSA_PREFILL_ARGS);
+                         VPSA_PREFILL_ARGS, rope);
     } else if (variant == 5) {
       hipLaunchKernelGGL((paged_prefill_kernel_v3<true, 1>), grid, block, 98304, stream,
                          VPSA_PREFILL_ARGS);
@@ -1583,6 +1622,17 @@ VPSA_EXPORT int vpsa_paged_prefill(const void* q, long q_stride, void* out, long
   }
 #undef VPSA_PREFILL_ARGS
   return 0;
+}
+
+VPSA_EXPORT int vpsa_paged_prefill(const void* q, long q_stride, void* out, long out_stride,
+                                   const void* cache, long page_stride, long v_offset,
+                                   const int* block_tables, int max_blocks, const int* cu_q,
+                                   const int* ctx_lens, const int* tile_seq, const int* tile_q0,
+                                   int num_tiles, int num_seqs, int tile_rows, int n_q, int n_kv,
+                                   float scale, hipStream_t stream) {
+  return vpsa_paged_prefill_rope(q, q_stride, out, out_stride, cache, page_stride, v_offset, block_tables,
+                                 max_blocks, cu_q, ctx_lens, tile_seq, tile_q0, num_tiles, num_seqs,
+                                 tile_rows, n_q, n_kv, scale, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------

@@ -171,6 +171,101 @@ VPSA_EXPORT int vpsa_rope_cache(void* qkv, const int* positions, const long* slo
 }
 
 // ---------------------------------------------------------------------------------
+// K/V of prefill rows -> paged cache, 32 consecutive rows of one KV head per workgroup.  The
+// query heads are not touched (the prefill attention kernel rotates them as it loads them) and
+// the rotated K goes to the cache only, not back into qkv.
+//
+// The per-token kernel above writes a token's V as 128 two-byte stores 64 bytes apart (the V
+// page keeps 32 keys of a channel together): 0.75 TB/s at 8192 rows.  Here V goes through a
+// transposing LDS tile so that a store instruction covers 32 consecutive keys of two channels:
+// 128 contiguous bytes when the rows' slots are consecutive, which they are within a sequence.
+// K: one thread per (row, 16-byte chunk c and its rotation partner c + 64 channels); the eight
+// chunks of a row and the rows of a tile land in contiguous runs of the [channel block][key][32]
+// page layout.
+// ---------------------------------------------------------------------------------
+#define KVT_ROWS 32
+#define KVT_LD 130  // LDS row stride in elements: 65 dwords, so 32 rows of one channel hit 32 banks
+
+__global__ __launch_bounds__(256) void kv_cache_tile_kernel(
+    const uint16_t* __restrict__ qkv, const int* __restrict__ positions, const long* __restrict__ slots,
+    const float* __restrict__ cos_sin, uint16_t* __restrict__ cache, long qkv_stride, int n_q,
+    int n_kv, long page_stride, long v_offset, int rotary, int n_rows) {
+  __shared__ uint16_t vt[KVT_ROWS * KVT_LD];
+  const int tid = threadIdx.x, kvh = blockIdx.y;
+  const int t0 = blockIdx.x * KVT_ROWS;
+  {
+    const int tok = t0 + (tid >> 3), c8 = tid & 7;
+    const long slot = tok < n_rows ? slots[tok] : -1;
+    if (slot >= 0) {
+      const uint16_t* src = qkv + (long)tok * qkv_stride + (n_q + kvh) * HEAD_DIM + 8 * c8;
+      u32x4 lo = *reinterpret_cast<const u32x4*>(src);
+      u32x4 hi = *reinterpret_cast<const u32x4*>(src + 64);
+      if (rotary) {
+        const float* cs = cos_sin + (long)positions[tok] * HEAD_DIM + 8 * c8;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(cs + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(cs + 64);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(cs + 68);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float ca = w < 2 ? c0[2 * w] : c1[2 * w - 4], cb = w < 2 ? c0[2 * w + 1] : c1[2 * w - 3];
+          const float sa = w < 2 ? s0[2 * w] : s1[2 * w - 4], sb = w < 2 ? s0[2 * w + 1] : s1[2 * w - 3];
+          const float x0 = bf16lo(lo[w]), x1 = bf16hi(lo[w]), y0 = bf16lo(hi[w]), y1 = bf16hi(hi[w]);
+          lo[w] = pack_bf16x2(x0 * ca - y0 * sa, x1 * cb - y1 * sb);
+          hi[w] = pack_bf16x2(y0 * ca + x0 * sa, y1 * cb + x1 * sb);
+        }
+      }
+      const long page = slot / PAGE;
+      const int off = (int)(slot % PAGE);
+      uint16_t* kd = cache + page * page_stride + (long)kvh * PAGE * HEAD_DIM;
+      *reinterpret_cast<u32x4*>(kd + k_elem_off(off, 8 * c8)) = lo;
+      *reinterpret_cast<u32x4*>(kd + k_elem_off(off, 64 + 8 * c8)) = hi;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int lt = (tid >> 4) + 16 * i, c = tid & 15;
+    const int tok = t0 + lt;
+    u32x4 v = (u32x4){0, 0, 0, 0};
+    if (tok < n_rows)
+      v = *reinterpret_cast<const u32x4*>(qkv + (long)tok * qkv_stride + (n_q + n_kv + kvh) * HEAD_DIM + 8 * c);
+    uint32_t* d = reinterpret_cast<uint32_t*>(vt + lt * KVT_LD + 8 * c);
+    d[0] = v[0];
+    d[1] = v[1];
+    d[2] = v[2];
+    d[3] = v[3];
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, lt = lane & 31;
+  const int tok = t0 + lt;
+  const long slot = tok < n_rows ? slots[tok] : -1;
+  if (slot >= 0) {
+    const long page = slot / PAGE;
+    const int off = (int)(slot % PAGE);
+    uint16_t* vd = cache + page * page_stride + v_offset + (long)kvh * HEAD_DIM * PAGE;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int ch = it * 8 + wave * 2 + (lane >> 5);
+      vd[v_elem_off(ch, off)] = vt[lt * KVT_LD + ch];
+    }
+  }
+}
+
+// Rows [0, n_rows) of qkv (already offset to the first prefill row, as are positions and slots):
+// K heads rotated and written to the cache, V heads written to the cache; qkv is left unchanged.
+VPSA_EXPORT int vpsa_kv_cache_write(const void* qkv, const int* positions, const long* slots,
+                                    const float* cos_sin, void* cache, int n_rows, long qkv_stride,
+                                    int n_q, int n_kv, long page_stride, long v_offset, int rotary,
+                                    hipStream_t stream) {
+  if (n_rows <= 0) return 0;
+  if ((qkv_stride & 7) || ((uintptr_t)qkv & 15) || n_kv > 65535) return -1;
+  hipLaunchKernelGGL(kv_cache_tile_kernel, dim3((n_rows + KVT_ROWS - 1) / KVT_ROWS, n_kv), dim3(256), 0,
+                     stream, (const uint16_t*)qkv, positions, slots, cos_sin, (uint16_t*)cache, qkv_stride,
+                     n_q, n_kv, page_stride, v_offset, rotary, n_rows);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
 // SwiGLU: out[t, i] = silu(x[t, i]) * x[t, inter + i];   x is [tokens, 2*inter].
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restrict__ x,

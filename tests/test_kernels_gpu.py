@@ -75,6 +75,16 @@ def test_rope_and_cache(n_q, n_kv):
     torch.testing.assert_close(pool.float(), pool_ref.float(), atol=2e-2, rtol=2e-2)
     # untouched layers stay bit-identical
     assert torch.equal(pool[:, 0], pool_ref[:, 0]) and torch.equal(pool[:, 2], pool_ref[:, 2])
+    # the tile kernel for prefill rows: same cache contents from scattered slots, a skipped row and
+    # a ragged last tile; qkv is read only
+    torch.manual_seed(3)
+    qkv2 = torch.randn(t, (n_q + 2 * n_kv) * hd, device=DEV).to(BF)
+    keep = qkv2.clone()
+    pool2 = _pool(pages, layers, n_kv)
+    ops.kv_cache_write(qkv2, pos, slots, cs, pool2, 1, n_q, n_kv, hd)
+    assert torch.equal(qkv2, keep)
+    torch.testing.assert_close(pool2.float(), pool_ref.float(), atol=2e-2, rtol=2e-2)
+    assert torch.equal(pool2[:, 0], pool_ref[:, 0]) and torch.equal(pool2[:, 2], pool_ref[:, 2])
 
 
 def _block_tables(n_seqs, max_pages, total_pages, seed):
@@ -152,6 +162,71 @@ def test_paged_prefill_matches_reference(n_q, n_kv, variant):
     ref.paged_prefill(q, out_ref, pool, 1, bt, cu, ctx_t, n_q, n_kv, hd, 1.0 / math.sqrt(hd))
     err = _rel_row_err(out, out_ref, n_q)
     assert err < REL_TOL, err
+
+
+@pytest.mark.parametrize("variant", [-1, 8, 9])
+@pytest.mark.parametrize("n_q,n_kv", [(32, 8), (8, 2)])
+def test_paged_prefill_rotates_queries_itself(n_q, n_kv, variant):
+    """Prefill rows: K / V go to the cache through the tile kernel (``kv_cache_write``: rotated K,
+    LDS-transposed V, nothing written back to qkv) and the fourth-generation attention kernel
+    rotates the query rows as it loads them.  Same output as rotating in place first, same cache
+    contents; decode rows in front keep the per-token pass."""
+    torch.manual_seed(9)
+    hd, layers = 128, 2
+    cases = [(200, 0), (33, 500), (1, 129), (64, 64), (97, 1000)]
+    q_lens = [c[0] for c in cases]
+    ctx = [c[0] + c[1] for c in cases]
+    nd = 3  # decode rows in front of the prefill rows, as in a mixed step
+    t = nd + sum(q_lens)
+    max_pages = (max(ctx) + ops.PAGE - 1) // ops.PAGE
+    pool = _v_offset_pool(len(cases) * max_pages + 3, layers, n_kv, seed=5)
+    bt = _block_tables(len(cases), max_pages, pool.shape[0], 6)
+    qkv = torch.randn(t, (n_q + 2 * n_kv) * hd, device=DEV).to(BF)
+    cs = ops.build_cos_sin(hd, 2048, 500000.0, device=DEV)
+    pos = [7, 70, 700]
+    slots = [-1, -1, -1]
+    for i, (n, pre) in enumerate(cases):
+        for r in range(n):
+            p_ = pre + r
+            pos.append(p_)
+            slots.append(int(bt[i, p_ // ops.PAGE]) * ops.PAGE + p_ % ops.PAGE)
+    pos = torch.tensor(pos, dtype=torch.int32, device=DEV)
+    slots = torch.tensor(slots, dtype=torch.int64, device=DEV)
+    prev = ops.set_prefill_variant(variant)
+    try:
+        rows = ops.prefill_tile_rows(q_lens, n_q, n_kv)
+        assert rows == 64 and ops.prefill_fuses_rope(n_q, n_kv, rows)
+        ops.set_prefill_variant(5)
+        assert not ops.prefill_fuses_rope(n_q, n_kv, rows)
+        ops.set_prefill_variant(variant)
+        cu = torch.tensor([0] + list(torch.tensor(q_lens).cumsum(0)), dtype=torch.int32, device=DEV)
+        ctx_t = torch.tensor(ctx, dtype=torch.int32, device=DEV)
+        ts, tq = ops.build_prefill_tiles(q_lens, n_q, n_kv, rows)
+        ts = torch.tensor(ts, dtype=torch.int32, device=DEV)
+        tq = torch.tensor(tq, dtype=torch.int32, device=DEV)
+        scale = 1.0 / math.sqrt(hd)
+        # unfused: rotate everything in place, then attend
+        a, pool_a = qkv.clone(), pool.clone()
+        ops.rope_and_cache(a, pos, slots, cs, pool_a, 1, n_q, n_kv, hd)
+        out_a = torch.zeros(t - nd, n_q * hd, device=DEV, dtype=BF)
+        ops.paged_prefill(a[nd:, : n_q * hd], out_a, pool_a, 1, bt, cu, ctx_t, ts, tq, n_q, n_kv, hd, scale, rows)
+        # fused
+        b, pool_b = qkv.clone(), pool.clone()
+        ops.rope_and_cache(b[:nd], pos[:nd], slots[:nd], cs, pool_b, 1, n_q, n_kv, hd)
+        ops.kv_cache_write(b[nd:], pos[nd:], slots[nd:], cs, pool_b, 1, n_q, n_kv, hd)
+        out_b = torch.zeros_like(out_a)
+        ops.paged_prefill(b[nd:, : n_q * hd], out_b, pool_b, 1, bt, cu, ctx_t, ts, tq, n_q, n_kv, hd, scale, rows,
+                          rope=cs)
+    finally:
+        ops.set_prefill_variant(prev)
+    torch.cuda.synchronize()
+    assert torch.equal(pool_a[:, 0], pool_b[:, 0]), "other layers untouched"
+    torch.testing.assert_close(pool_a.float(), pool_b.float(), atol=2e-2, rtol=2e-2)
+    assert (pool_a != pool_b).float().mean().item() < 0.02, "at most rounding-level differences in K"
+    assert torch.equal(a[:nd], b[:nd]), "decode rows are rotated in place either way"
+    assert torch.equal(b[nd:], qkv[nd:]), "prefill rows of qkv stay as they were"
+    err = _rel_row_err(out_b, out_a, n_q)
+    assert err < 8e-3, err  # the two rotations may round a query element to neighbouring bf16 values
 
 
 @pytest.mark.parametrize("variant", [2, 4, 8])

@@ -27,7 +27,7 @@ def _kernels():
     if _lib is None:
         lib = _native.load("vpsa_kernels")
         for name in (
-            "vpsa_rmsnorm", "vpsa_rope_cache", "vpsa_silu_mul", "vpsa_argmax_bf16",
+            "vpsa_rmsnorm", "vpsa_rope_cache", "vpsa_kv_cache_write", "vpsa_paged_prefill_rope", "vpsa_prefill_fuses_rope", "vpsa_silu_mul", "vpsa_argmax_bf16",
             "vpsa_paged_prefill", "vpsa_set_prefill_variant", "vpsa_prefill_tile_rows", "vpsa_set_decode_variant", "vpsa_paged_decode", "vpsa_kv_gather_pages",
             "vpsa_kv_scatter_pages", "vpsa_cachegen_encode", "vpsa_cachegen_decode",
             "vpsa_moe_topk_softmax", "vpsa_moe_align", "vpsa_moe_permute", "vpsa_moe_combine",
@@ -185,11 +185,29 @@ def attention_block(qkv, pool, layer, meta, n_q, n_kv, head_dim, scale, cos_sin,
     return _attention_block(qkv, pool, layer, meta, n_q, n_kv, d, scale, cos_sin, rotary)
 
 
+def prefill_fuses_rope(n_q: int, n_kv: int, tile_rows) -> bool:
+    """True when the prefill kernel that will run rotates its query rows itself."""
+    return bool(tile_rows) and int(_kernels().vpsa_prefill_fuses_rope(c_int(n_q), c_int(n_kv), c_int(tile_rows))) == 1
+
+
 def _attention_block(qkv, pool, layer, meta, n_q, n_kv, d, scale, cos_sin, rotary):
-    rope_and_cache(qkv, meta.positions, meta.slots, cos_sin, pool, layer, n_q, n_kv, d, rotary)
+    nd = meta.num_decode
+    # Prefill rows: the attention kernel applies the rotary embedding to the query rows as it
+    # loads them, and their K / V go to the cache through the tile kernel (rotated K, V transposed
+    # in LDS so that the page's [channel][32 keys] runs are written whole).  Decode rows keep the
+    # per-token pass with the in-place rotation: their kernel reads q as stored.
+    fuse = (rotary and meta.num_prefill_seqs > 0 and not _generic_attention(qkv, d)
+            and prefill_fuses_rope(n_q, n_kv, meta.pre_tile_rows))
+    if fuse:
+        if nd > 0:
+            rope_and_cache(qkv[:nd], meta.positions[:nd], meta.slots[:nd], cos_sin, pool, layer, n_q, n_kv, d,
+                           rotary)
+        kv_cache_write(qkv[nd:], meta.positions[nd:], meta.slots[nd:], cos_sin, pool, layer, n_q, n_kv, d,
+                       rotary)
+    else:
+        rope_and_cache(qkv, meta.positions, meta.slots, cos_sin, pool, layer, n_q, n_kv, d, rotary)
     t = qkv.shape[0]
     out = torch.empty((t, n_q * d), dtype=qkv.dtype, device=qkv.device)
-    nd = meta.num_decode
     q = qkv[:, : n_q * d]
     if nd > 0:
         paged_decode(q[:nd], out[:nd], pool, layer, meta.dec_block_tables, meta.dec_ctx_lens, n_q, n_kv, d,
@@ -197,8 +215,23 @@ def _attention_block(qkv, pool, layer, meta, n_q, n_kv, d, scale, cos_sin, rotar
                      getattr(meta, "dec_ws_ml", None))
     if meta.num_prefill_seqs > 0:
         paged_prefill(q[nd:], out[nd:], pool, layer, meta.pre_block_tables, meta.pre_cu_q, meta.pre_ctx_lens,
-                      meta.pre_tile_seq, meta.pre_tile_q0, n_q, n_kv, d, scale, meta.pre_tile_rows)
+                      meta.pre_tile_seq, meta.pre_tile_q0, n_q, n_kv, d, scale, meta.pre_tile_rows,
+                      rope=cos_sin if fuse else None)
     return out
+
+
+def kv_cache_write(qkv, positions, slots, cos_sin, pool, layer, n_q, n_kv, head_dim, rotary=True):
+    """K (rotated) and V heads of ``qkv`` rows -> paged cache; ``qkv`` itself is not modified and
+    the query heads are not read.  For prefill rows whose queries ``paged_prefill(rope=)`` rotates."""
+    _bf16_cuda(qkv, pool)
+    assert positions.dtype == torch.int32 and slots.dtype == torch.int64
+    assert cos_sin.dtype == torch.float32 and cos_sin.shape[1] == head_dim == 128
+    base = pool.data_ptr() + layer * pool.stride(1) * 2
+    rc = _kernels().vpsa_kv_cache_write(_p(qkv), _p(positions), _p(slots), _p(cos_sin), c_void_p(base),
+                                        c_int(qkv.shape[0]), c_long(qkv.stride(0)), c_int(n_q),
+                                        c_int(n_kv), c_long(pool.stride(0)), c_long(pool.stride(2)),
+                                        c_int(1 if rotary else 0), _stream())
+    _check(rc, "kv_cache_write")
 
 
 def rope_and_cache(qkv, positions, slots, cos_sin, pool, layer, n_q, n_kv, head_dim, rotary=True):
@@ -247,9 +280,11 @@ def build_prefill_tiles(q_lens, n_q, n_kv, rows=None, ctx_lens=None):
 
 
 def paged_prefill(q, out, pool, layer, block_tables, cu_q, ctx_lens, tile_seq, tile_q0, n_q, n_kv,
-                  head_dim, scale, tile_rows=None):
+                  head_dim, scale, tile_rows=None, rope=None):
     """``tile_rows``: the tile height ``tile_seq`` / ``tile_q0`` were built for (default: the
-    32-row-wave layout of the first two kernel generations)."""
+    32-row-wave layout of the first two kernel generations).  ``rope``: the [position, head_dim]
+    fp32 cos / sin table when ``q`` holds unrotated rows (``prefill_fuses_rope`` says whether the
+    kernel that will run takes it)."""
     if _generic_attention(q, head_dim):
         return reference.paged_prefill(q, out, pool, layer, block_tables, cu_q, ctx_lens, n_q,
                                        n_kv, head_dim, scale)
@@ -261,12 +296,13 @@ def paged_prefill(q, out, pool, layer, block_tables, cu_q, ctx_lens, tile_seq, t
     if tile_rows is None:
         tile_rows = 32 * (4 // min(n_q // n_kv, 4))
     base = pool.data_ptr() + layer * pool.stride(1) * 2
-    rc = _kernels().vpsa_paged_prefill(
+    assert rope is None or (rope.dtype == torch.float32 and rope.is_contiguous() and rope.shape[1] == head_dim)
+    rc = _kernels().vpsa_paged_prefill_rope(
         _p(q), c_long(q.stride(0)), _p(out), c_long(out.stride(0)), c_void_p(base),
         c_long(pool.stride(0)), c_long(pool.stride(2)), _p(block_tables),
         c_int(block_tables.stride(0)), _p(cu_q), _p(ctx_lens), _p(tile_seq), _p(tile_q0),
         c_int(tile_seq.numel()), c_int(ctx_lens.numel()), c_int(tile_rows), c_int(n_q), c_int(n_kv),
-        c_float(scale), _stream())
+        c_float(scale), _p(rope), _stream())
     _check(rc, "paged_prefill")
 
 
