@@ -138,6 +138,26 @@ def test_encoder_decoder_match_hf(hf_checkpoint):
     assert (got_step - want[:, -1]).abs().max().item() < 2e-4
 
 
+def test_width3_convolutions_as_gemms_match_conv1d():
+    """The encoder front end computes its two convolutions as one GEMM each over an overlapping
+    strided view of the padded channels-last input: same numbers as ``conv1d`` for stride 1 and
+    2, even and odd lengths."""
+    import torch.nn.functional as F
+
+    cfg = W.WhisperConfig(d_model=32, num_mel_bins=10)
+    m = W.WhisperModel(cfg, torch.float32, torch.device("cpu"))
+    g = torch.Generator().manual_seed(0)
+    for t, stride, ci, co in ((40, 1, 10, 32), (41, 2, 32, 32), (40, 2, 32, 32), (7, 1, 10, 32)):
+        m.w["c.weight"] = torch.randn(co, ci, 3, generator=g)
+        m.w["c.bias"] = torch.randn(co, generator=g)
+        m._conv_w.clear()
+        x = torch.randn(2, ci, t, generator=g)
+        want = F.conv1d(x, m.w["c.weight"], m.w["c.bias"], stride=stride, padding=1).transpose(1, 2)
+        got = m._conv3(x.transpose(1, 2), "c", stride)
+        assert got.shape == want.shape
+        assert (got - want).abs().max().item() < 1e-4
+
+
 def test_graph_decode_step_reproduces_the_eager_loop(hf_checkpoint):
     """The static-buffer decode step the GPU captures as a graph (token, position and finished
     flags on the device, history read back at the end), replayed here without a capture: same
