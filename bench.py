@@ -20,7 +20,7 @@ users (default 40 per GPU = 320 on 8 GPUs), shared system prompt 1000 tokens, pe
 history 20000 tokens, 100-token answers, streamed chat completions with temperature 0.
 A *step* is one conversation round: every user sends its next turn and the round ends when
 every answer has been streamed back.  Warm-up rounds use separate throw-away users; the
-timed region starts with fresh users, so round 1 of the timed region is the cold 21k-token
+timed region starts with fresh users, so the first timed conversation round is the cold 21k-token
 prefill of every user and later rounds hit the KV cache.  Weak scaling: per-GPU users fixed.
 
 Prints one JSON line: value = aggregate output tokens/s over all GPUs (the throughput half
