@@ -291,6 +291,34 @@ def test_speech_graph_decode_matches_the_eager_loop_on_gpu():
     assert all(tok < cfg.eos_token_id for x in toks for tok in x)
 
 
+def test_speech_replica_sleeps_and_wakes_with_its_graphs_on_gpu():
+    """A speech replica on the GPU: graphs captured at start, the same transcript before a level-1
+    sleep and after waking (weights moved to the host and back, graphs and derived weights
+    rebuilt), sampling requests served by the eager loop next to greedy ones."""
+    import numpy as np
+
+    from vllm_production_stack_amd.engine.speech import SpeechEngine
+
+    cfg = EngineConfig(model="tiny-whisper", device="cuda", max_num_seqs=4)
+    eng = SpeechEngine(cfg)
+    try:
+        t = np.arange(16000 * 2) / 16000.0
+        wave = (0.3 * np.sin(2 * np.pi * 440.0 * t)).astype(np.float32)
+        eng.model.cfg.max_target_positions = 40  # random weights never emit end-of-text
+        eng.model.drop_graphs()
+        first = eng.transcribe(wave)
+        assert eng.model._gstate is not None and eng.model._gstate["graphs"], "greedy requests replay graphs"
+        assert len(first) == 1 and len(first[0]) == 36
+        freed = eng.sleep(1)
+        assert freed > 0 and eng.is_sleeping and eng.model._gstate is None
+        eng.wake_up()
+        assert eng.transcribe(wave) == first
+        sampled = eng.transcribe(wave, temperature=0.8)
+        assert len(sampled) == 1 and len(sampled[0]) == 36
+    finally:
+        eng.shutdown()
+
+
 def test_opt_125m_serves_on_the_hip_kernels_and_other_head_sizes_on_the_generic_path():
     """OPT-125m (head_dim 64) runs the MFMA attention kernels with padded heads and HIP-graph
     decode; a head size the kernels do not cover (32) takes the PyTorch attention definitions,
