@@ -234,7 +234,7 @@ class TransformerModel:
             a, b = off[ex], off[ex + 1]
             if b > a:
                 gu = F.linear(xs[a:b], lw.w13[ex])
-                ys[a:b] = F.linear(ops.silu_and_mul(gu), lw.w2[ex])
+                torch.matmul(ops.silu_and_mul(gu), lw.w2[ex].t(), out=ys[a:b])  # no staging copy
         return ops.moe_combine(ys, w, pos, t)
 
     def _lora(self, name: str, layer: int, x: torch.Tensor, y: torch.Tensor, meta: BatchMeta):
