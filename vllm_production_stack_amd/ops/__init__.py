@@ -192,18 +192,21 @@ def prefill_fuses_rope(n_q: int, n_kv: int, tile_rows) -> bool:
 
 def _attention_block(qkv, pool, layer, meta, n_q, n_kv, d, scale, cos_sin, rotary):
     nd = meta.num_decode
-    # Prefill rows: the attention kernel applies the rotary embedding to the query rows as it
-    # loads them, and their K / V go to the cache through the tile kernel (rotated K, V transposed
-    # in LDS so that the page's [channel][32 keys] runs are written whole).  Decode rows keep the
-    # per-token pass with the in-place rotation: their kernel reads q as stored.
-    fuse = (rotary and meta.num_prefill_seqs > 0 and not _generic_attention(qkv, d)
-            and prefill_fuses_rope(n_q, n_kv, meta.pre_tile_rows))
-    if fuse:
+    # Prefill rows: their K / V go to the cache through the tile kernel (rotated K, V transposed
+    # in LDS so that the page's [channel][32 keys] runs are written whole), and the query rows are
+    # rotated by the attention kernel as it loads them when the kernel that will run can do that
+    # (GQA groups of 4 and multiples), else in place by a pass over the query heads only.  Decode
+    # rows keep the per-token pass with the in-place rotation: their kernel reads q as stored.
+    tiled = meta.num_prefill_seqs > 0 and not _generic_attention(qkv, d)
+    fuse = tiled and rotary and prefill_fuses_rope(n_q, n_kv, meta.pre_tile_rows)
+    if tiled:
         if nd > 0:
             rope_and_cache(qkv[:nd], meta.positions[:nd], meta.slots[:nd], cos_sin, pool, layer, n_q, n_kv, d,
                            rotary)
         kv_cache_write(qkv[nd:], meta.positions[nd:], meta.slots[nd:], cos_sin, pool, layer, n_q, n_kv, d,
                        rotary)
+        if rotary and not fuse:
+            rope_and_cache(qkv[nd:], meta.positions[nd:], None, cos_sin, pool, layer, n_q, 0, d, True)
     else:
         rope_and_cache(qkv, meta.positions, meta.slots, cos_sin, pool, layer, n_q, n_kv, d, rotary)
     t = qkv.shape[0]
@@ -222,7 +225,8 @@ def _attention_block(qkv, pool, layer, meta, n_q, n_kv, d, scale, cos_sin, rotar
 
 def kv_cache_write(qkv, positions, slots, cos_sin, pool, layer, n_q, n_kv, head_dim, rotary=True):
     """K (rotated) and V heads of ``qkv`` rows -> paged cache; ``qkv`` itself is not modified and
-    the query heads are not read.  For prefill rows whose queries ``paged_prefill(rope=)`` rotates."""
+    the query heads are not read (prefill rows: their queries are rotated by ``paged_prefill(rope=)``
+    or by a query-only ``rope_and_cache`` pass).  ``rotary=False`` writes K as it is."""
     _bf16_cuda(qkv, pool)
     assert positions.dtype == torch.int32 and slots.dtype == torch.int64
     assert cos_sin.dtype == torch.float32 and cos_sin.shape[1] == head_dim == 128
