@@ -480,6 +480,25 @@ def test_dense_attention_matches_fp32(b, heads, tq, tk):
     assert not ops.dense_attention_supported(q.float(), k.float(), v.float(), heads)
 
 
+def test_qkv_projection_split_for_prefill_sized_batches():
+    """From 4096 rows on the fused q/k/v projection is two library GEMMs writing into one buffer
+    (the library is slow at the fused width): same result as the single call, one contiguous
+    [rows, q + k + v] output either way."""
+    torch.manual_seed(21)
+    n_q_cols, n = 1024, 1536
+    w = (torch.randn(n, 512, device=DEV) * 0.05).to(BF)
+    for rows in (ops.SPLIT_QKV_MIN_ROWS, 64):
+        x = torch.randn(rows, 512, device=DEV).to(BF)
+        got = ops.qkv_linear(x, w, None, n_q_cols)
+        want = torch.nn.functional.linear(x.float(), w.float())
+        assert got.shape == (rows, n) and got.is_contiguous()
+        err = (got.float() - want).abs().max().item() / want.abs().max().item()
+        assert err < 1e-2, err
+    b = torch.randn(n, device=DEV).to(BF)
+    x = torch.randn(ops.SPLIT_QKV_MIN_ROWS, 512, device=DEV).to(BF)
+    assert torch.equal(ops.qkv_linear(x, w, b, n_q_cols), ops.linear(x, w, b)), "a bias keeps the single call"
+
+
 def test_skinny_linear_strided_rows_and_fallback():
     torch.manual_seed(3)
     base = torch.randn(9, 2 * 4096, device=DEV).to(BF)

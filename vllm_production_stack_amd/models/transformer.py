@@ -262,7 +262,7 @@ class TransformerModel:
                 x = ops.rms_norm(h, lw.ln1, cfg.norm_eps)
             else:
                 x = ops.rms_norm(h, lw.ln1, cfg.norm_eps, residual)
-            qkv = self._lora("qkv", gl, x, ops.linear(x, lw.wqkv, lw.bqkv), meta)
+            qkv = self._lora("qkv", gl, x, ops.qkv_linear(x, lw.wqkv, lw.bqkv, self.n_q * self.head_dim), meta)
             attn = self._attention(qkv, pool, li, meta)
             h = self._lora("o", gl, attn, ops.linear(attn, lw.wo), meta)
             h = tp_all_reduce(h)

@@ -511,6 +511,25 @@ def linear(x, w, bias=None, packed=None):
     return torch.nn.functional.linear(x, w, bias)
 
 
+# The library's pick for the fused q/k/v width of Llama-3-8B (6144 columns) is 12-14 % slower per
+# column than its pick for 4096 and 2048 columns at 8192 rows, 7 % at 4096 rows, and faster below
+# (profiles/r2_gemm_split_probe.jsonl); other projections gain nothing from a split.
+SPLIT_QKV_MIN_ROWS = 4096
+
+
+def qkv_linear(x, w, bias, q_cols: int):
+    """The fused q/k/v projection.  Prefill-sized batches without a bias issue it as two library
+    GEMMs, [q | k v], each writing its column range of ONE output buffer (same bits as the single
+    call); everything else is ``linear``."""
+    if (bias is None and x.is_cuda and x.dim() == 2 and x.shape[0] >= SPLIT_QKV_MIN_ROWS
+            and x.dtype == torch.bfloat16 and 0 < q_cols < w.shape[0]):
+        out = torch.empty((x.shape[0], w.shape[0]), dtype=x.dtype, device=x.device)
+        torch.matmul(x, w[:q_cols].t(), out=out[:, :q_cols])
+        torch.matmul(x, w[q_cols:].t(), out=out[:, q_cols:])
+        return out
+    return linear(x, w, bias)
+
+
 def gate_up_silu(x, w_gate_up, packed=None):
     """silu(x @ Wg.T) * (x @ Wu.T) for ``w_gate_up = [Wg; Wu]``: fused in one kernel for
     decode batches, library GEMM + activation kernel otherwise.  ``packed`` as in ``linear``."""
