@@ -30,7 +30,8 @@ TARGETS = {
         "hip",
         ["kernels/elementwise.hip", "kernels/attention.hip", "kernels/kvcache.hip", "kernels/moe.hip",
          "kernels/lora.hip", "kernels/gemm.hip", "kernels/rans.hip", "kernels/sampling.hip",
-         "kernels/grouped_gemm.hip", "kernels/packed_gemm.hip", "kernels/dense_attention.hip"],
+         "kernels/grouped_gemm.hip", "kernels/packed_gemm.hip", "kernels/dense_attention.hip",
+         "kernels/tile_gemm.hip"],
         [],
     ),
     "vpsa_kvio": ("hip", ["kvio/kvio.cpp"], []),

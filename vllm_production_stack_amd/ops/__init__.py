@@ -36,6 +36,7 @@ def _kernels():
             "vpsa_stream_gemm_splits", "vpsa_set_stream_targets", "vpsa_rans_encode", "vpsa_rans_pack",
             "vpsa_rans_decode", "vpsa_sample", "vpsa_grouped_gemm", "vpsa_packed_gemm",
             "vpsa_packed_gemm_splits", "vpsa_set_packed_target", "vpsa_dense_decode_attention", "vpsa_dense_attention",
+            "vpsa_tile_gemm",
         ):
             getattr(lib, name).restype = c_int
         if os.environ.get("VPSA_PREFILL_VARIANT"):  # pin one prefill kernel for A/B runs
@@ -861,6 +862,46 @@ def grouped_gemm(a, w, offsets, rows=None, arow_idx=None, silu_mul=False, out=No
                                       _p(w), _p(offsets), c_int(g), _p(out), c_long(out.stride(0)), c_int(rows),
                                       c_int(n), c_int(k), c_int(1 if silu_mul else 0), _stream())
     _check(rc, "grouped_gemm")
+    return out
+
+
+def tile_gemm_supported(n: int, k: int, silu_mul: bool = False) -> bool:
+    return k % 64 == 0 and n % 8 == 0 and (not silu_mul or (n // 2) % 32 == 0) and n * k * 2 < 2 ** 32
+
+
+def tile_gemm(a, w, offsets=None, rows=None, arow_idx=None, silu_mul=False, residual=None, out=None):
+    """The prefill GEMM (``csrc/kernels/tile_gemm.hip``): out[r] = epilogue(a[arow_idx[r] or r] @ w[g]^T).
+
+    a [*, K] bf16; w [N, K] (dense) or [G, N, K] (grouped, with offsets [G + 1] int32 ON THE DEVICE:
+    group g owns output rows offsets[g] .. offsets[g+1], no host synchronisation).  silu_mul: w is
+    [gate rows | up rows], out = silu(gate) * up, [rows, N / 2].  residual [rows, N]: out = product +
+    residual (``out`` may be ``residual`` itself).  Rows at or past offsets[G] are left unwritten."""
+    if w.dim() == 2:
+        w = w.unsqueeze(0)
+    g, n, k = w.shape
+    if rows is None:
+        rows = a.shape[0] if arow_idx is None else arow_idx.numel()
+    n_out = n // 2 if silu_mul else n
+    _bf16_cuda(a, w, residual)
+    assert w.is_contiguous() and a.stride(-1) == 1 and a.shape[1] == k
+    assert not (silu_mul and residual is not None)
+    if offsets is not None:
+        assert offsets.dtype == torch.int32 and offsets.numel() == g + 1 and offsets.is_cuda
+    else:
+        assert g == 1
+    if arow_idx is not None:
+        assert arow_idx.dtype == torch.int32 and arow_idx.is_cuda and arow_idx.numel() >= rows
+    if out is None:
+        out = torch.empty((rows, n_out), dtype=a.dtype, device=a.device)
+    assert out.stride(-1) == 1 and out.shape[0] >= rows and out.shape[1] == n_out
+    if residual is not None:
+        assert residual.stride(-1) == 1 and residual.shape[0] >= rows and residual.shape[1] == n_out
+    epi = 1 if silu_mul else (2 if residual is not None else 0)
+    rc = _kernels().vpsa_tile_gemm(_p(a), c_long(a.stride(0)), _p(arow_idx), _p(w), _p(offsets), c_int(g), _p(out),
+                                   c_long(out.stride(0)), c_int(rows), c_int(n), c_int(k), c_int(epi), _p(residual),
+                                   c_long(residual.stride(0) if residual is not None else 0), c_long(a.shape[0]),
+                                   _stream())
+    _check(rc, "tile_gemm")
     return out
 
 
