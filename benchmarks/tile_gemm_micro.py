@@ -85,10 +85,14 @@ def check():
         sys.exit(1)
 
 
-def bench(m, rounds, inner):
+def bench(m, rounds, inner, dbg=False, gauss=False):
     for name, n, k in (("qkv", 6144, 4096), ("o", 4096, 4096), ("gate_up", 28672, 4096), ("down", 4096, 14336)):
-        ws = [rnd(n, k, scale=0.05) for _ in range(3)]
-        x = rnd(m, k)
+        if gauss:  # what a random-init model feeds its projections: unit-variance rows, weights of std 0.02
+            ws = [(torch.randn(n, k, device=DEV) * 0.02).to(torch.bfloat16) for _ in range(3)]
+            x = torch.randn(m, k, device=DEV).to(torch.bfloat16)
+        else:
+            ws = [rnd(n, k, scale=0.05) for _ in range(3)]
+            x = rnd(m, k)
         off = torch.tensor([0, m], dtype=torch.int32, device=DEV)
         st = {"i": 0}
 
@@ -101,6 +105,21 @@ def bench(m, rounds, inner):
             "tile": lambda: ops.tile_gemm(x, nxt()),
             "grouped_r2": lambda: ops.grouped_gemm(x, nxt().unsqueeze(0), off),
         }
+        if dbg:
+            lib = ops._kernels()
+
+            def with_dbg(d):
+                def run():
+                    lib.vpsa_tile_gemm_debug(d)
+                    r = ops.tile_gemm(x, nxt())
+                    lib.vpsa_tile_gemm_debug(0)
+                    return r
+                return run
+
+            variants["tile_no_loads(wrong)"] = with_dbg(1)
+            variants["tile_no_frag_reads(wrong)"] = with_dbg(2)
+            variants["tile_neither(wrong)"] = with_dbg(3)
+            variants["tile_loads_hit_cache(wrong)"] = with_dbg(4)
         if name == "gate_up":
             variants["library+silu_mul"] = lambda: ops.silu_and_mul(F.linear(x, nxt()))
             variants["tile_swiglu"] = lambda: ops.tile_gemm(x, nxt(), silu_mul=True)
@@ -135,10 +154,12 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--inner", type=int, default=10)
     ap.add_argument("--skip-check", action="store_true")
+    ap.add_argument("--gauss", action="store_true", help="normal operands (std 1 activations, std 0.02 weights) instead of uniform")
+    ap.add_argument("--dbg", action="store_true", help="add the timing experiments (wrong results) to the rounds")
     a = ap.parse_args()
     if not a.skip_check:
         check()
-    bench(a.m, a.rounds, a.inner)
+    bench(a.m, a.rounds, a.inner, a.dbg, a.gauss)
 
 
 if __name__ == "__main__":

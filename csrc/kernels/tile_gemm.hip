@@ -52,7 +52,10 @@ __device__ __forceinline__ void tg_glds16(const char* gptr, char* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr, (tg_lds_ptr_t)lds_dst, 16, 0, 0);
 }
 
-template <int EPI>
+// DBG: timing experiments with WRONG results (bit 0: no loads inside the K loop, bit 1: no fragment
+// reads inside the K loop, bit 2: every load inside the K loop re-requests K tile 0, i.e. hits in
+// cache); 0 in every production launch.
+template <int EPI, int DBG>
 __global__ __launch_bounds__(512, 2) void tile_gemm_kernel(
     const uint16_t* __restrict__ a, long lda, const int* __restrict__ arow_idx,
     const uint16_t* __restrict__ w, long w_group_stride, const int* __restrict__ offsets, int n_groups, int max_rows,
@@ -141,8 +144,11 @@ __global__ __launch_bounds__(512, 2) void tile_gemm_kernel(
   }
   const int k_tiles = k_total / TG_BK;
   char* const fill_base = lds + wave * 1024;
+  bool in_loop = false;
   auto stage = [&](int which, int buf, int kt) {
-    const int ktc = kt < k_tiles ? kt : k_tiles - 1;  // past the end: re-request the last tile into a free slot
+    if ((DBG & 1) && in_loop) return;
+    int ktc = kt < k_tiles ? kt : k_tiles - 1;  // past the end: re-request the last tile into a free slot
+    if ((DBG & 4) && in_loop) ktc = 0;
     const char* base = (which < 2 ? a_base : w_base) + (long)ktc * (TG_BK * 2);
     tg_glds16(base + src_off[which][0], fill_base + buf * TG_BUF + which * TG_HT);
     tg_glds16(base + src_off[which][1], fill_base + buf * TG_BUF + which * TG_HT + 8192);
@@ -168,6 +174,7 @@ __global__ __launch_bounds__(512, 2) void tile_gemm_kernel(
   bf16x8 wb[2][2][2];   // weight fragments of both quadrant columns: [quadrant column][column tile][k step]
 
   auto read_w = [&](int buf, int nh) {
+    if ((DBG & 2) && in_loop) return;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       wb[nh][ni][0] = *reinterpret_cast<const bf16x8*>(lds + buf * TG_BUF + nh * TG_HT + ni * 2048 + w_rd + sl0);
@@ -175,6 +182,7 @@ __global__ __launch_bounds__(512, 2) void tile_gemm_kernel(
     }
   };
   auto read_x = [&](int buf, int mh) {
+    if ((DBG & 2) && in_loop) return;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       xa[mi][0] = *reinterpret_cast<const bf16x8*>(lds + buf * TG_BUF + mh * TG_HT + mi * 2048 + x_rd + sl0);
@@ -215,7 +223,8 @@ __global__ __launch_bounds__(512, 2) void tile_gemm_kernel(
   stage(2, 1, 1);
   stage(0, 1, 1);
   stage(3, 1, 1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  stage(1, 1, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   TG_BAR();
   if (wr == 1) TG_BAR();  // the second wave row runs one barrier behind the first
 
@@ -233,8 +242,6 @@ __global__ __launch_bounds__(512, 2) void tile_gemm_kernel(
     TG_SB();                                                    \
     read_x(B, 0);                                               \
     TG_SB();                                                    \
-    stage(1, (B) ^ 1, (KT) + 1);                                \
-    TG_SB();                                                    \
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");          \
     TG_BAR();                                                   \
     TG_LGKM0();                                                 \
@@ -250,18 +257,24 @@ __global__ __launch_bounds__(512, 2) void tile_gemm_kernel(
     read_x(B, 1);                                               \
     TG_SB();                                                    \
     stage(0, B, (KT) + 2);                                      \
-    TG_BAR();                                                   \
+    TG_SB();                                                    \
     TG_LGKM0();                                                 \
+    TG_BAR();                                                   \
     mma(1, 1);                                                  \
     TG_BAR();                                                   \
     stage(3, B, (KT) + 2);                                      \
+    stage(1, B, (KT) + 2);                                      \
     TG_SB();                                                    \
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            \
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            \
     TG_BAR();                                                   \
     mma(1, 0);                                                  \
     TG_BAR();                                                   \
   } while (0)
 
+  if (DBG) {
+    read_w(0, 0); read_w(0, 1); read_x(0, 0);
+    in_loop = true;
+  }
   int kt = 0;
   for (; kt + 1 < k_tiles; kt += 2) {
     TG_TILE(0, kt);
@@ -320,6 +333,13 @@ __global__ __launch_bounds__(512, 2) void tile_gemm_kernel(
   }
 }
 
+static int g_tg_debug = 0;
+VPSA_EXPORT int vpsa_tile_gemm_debug(int v) {
+  int old = g_tg_debug;
+  g_tg_debug = v;
+  return old;
+}
+
 // a [*, K] bf16 (row stride lda elements, 16-byte aligned rows); arow_idx [rows] int32 or null (null:
 // output row r reads A row r); w [G, N, K] contiguous; offsets [G + 1] int32 on the device with
 // offsets[G] <= max_rows, or null (one group of max_rows rows); c [max_rows, N] (SwiGLU: N / 2
@@ -341,22 +361,26 @@ VPSA_EXPORT int vpsa_tile_gemm(const void* a, long lda, const void* arow_idx, co
   const long blocks = (long)n_tiles * m_tiles_max;
   if (blocks > 0x7fffffffL) return -1;
   const long wstride = (long)n * k;
-#define TG_LAUNCH(E)                                                                                                 \
+#define TG_LAUNCH(E, D)                                                                                               \
   do {                                                                                                               \
     static bool attr_set = false;                                                                                    \
     if (!attr_set) {                                                                                                 \
-      if (hipFuncSetAttribute((const void*)tile_gemm_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, TG_LDS) != \
+      if (hipFuncSetAttribute((const void*)tile_gemm_kernel<E, D>, hipFuncAttributeMaxDynamicSharedMemorySize, TG_LDS) != \
           hipSuccess)                                                                                                \
         return -2;                                                                                                   \
       attr_set = true;                                                                                               \
     }                                                                                                                \
-    tile_gemm_kernel<E><<<dim3((unsigned)blocks), dim3(512), TG_LDS, stream>>>(                                       \
+    tile_gemm_kernel<E, D><<<dim3((unsigned)blocks), dim3(512), TG_LDS, stream>>>(                                       \
         (const uint16_t*)a, lda, (const int*)arow_idx, (const uint16_t*)w, wstride, (const int*)offsets, n_groups,   \
         max_rows, (uint16_t*)c, ldc, (const uint16_t*)resid, ldr, n, k, n_tiles);                                    \
   } while (0)
-  if (epi == TG_EPI_SWIGLU) TG_LAUNCH(TG_EPI_SWIGLU);
-  else if (epi == TG_EPI_RESIDUAL) TG_LAUNCH(TG_EPI_RESIDUAL);
-  else TG_LAUNCH(TG_EPI_PLAIN);
+  if (epi == TG_EPI_SWIGLU) TG_LAUNCH(TG_EPI_SWIGLU, 0);
+  else if (epi == TG_EPI_RESIDUAL) TG_LAUNCH(TG_EPI_RESIDUAL, 0);
+  else if (g_tg_debug == 1) TG_LAUNCH(TG_EPI_PLAIN, 1);
+  else if (g_tg_debug == 2) TG_LAUNCH(TG_EPI_PLAIN, 2);
+  else if (g_tg_debug == 3) TG_LAUNCH(TG_EPI_PLAIN, 3);
+  else if (g_tg_debug == 4) TG_LAUNCH(TG_EPI_PLAIN, 4);
+  else TG_LAUNCH(TG_EPI_PLAIN, 0);
 #undef TG_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -829,6 +829,111 @@ def test_grouped_gemm_gathered_rows_and_fused_swiglu():
         assert err < 8e-3, (ex, err)
 
 
+def _rel(got, exp):
+    return (got.float() - exp).abs().max().item() / exp.abs().max().clamp_min(1e-9).item()
+
+
+@pytest.mark.parametrize("m,n,k", [
+    (1, 8, 64), (255, 264, 128), (256, 256, 64), (257, 512, 192), (700, 1032, 320), (2048, 6144, 4096),
+    (4616, 4096, 4096), (300, 4096, 14336)])
+def test_tile_gemm_against_fp32(m, n, k):
+    """The prefill GEMM kernel (256 x 256 tiles, 16x16x32 MFMA, ping-pong wave rows) against the fp32
+    product: ragged M, N that is not a multiple of the tile, one and many K tiles (odd counts too),
+    Llama-3-8B projection shapes; plain store, residual epilogue (separate output and in place),
+    bias (a residual of row stride 0), rows beyond the problem untouched."""
+    torch.manual_seed(41)
+    x = (torch.rand(m, k, device=DEV) * 2 - 1).to(BF)
+    w = ((torch.rand(n, k, device=DEV) * 2 - 1) * 0.1).to(BF)
+    ref = x.float() @ w.float().t()
+    out = torch.full((m + 3, n), 7.0, dtype=BF, device=DEV)
+    ops.tile_gemm(x, w, out=out, rows=m)
+    assert _rel(out[:m], ref) < 6e-3
+    assert (out[m:] == 7.0).all()
+    r = (torch.rand(m, n, device=DEV) * 2 - 1).to(BF)
+    assert _rel(ops.tile_gemm(x, w, residual=r), ref + r.float()) < 6e-3
+    r2 = r.clone()
+    ops.tile_gemm(x, w, residual=r2, out=r2)
+    assert _rel(r2, ref + r.float()) < 6e-3
+    b = (torch.rand(n, device=DEV) * 2 - 1).to(BF)
+    assert _rel(ops.tile_gemm(x, w, residual=b.view(1, -1).expand(m, -1)), ref + b.float()) < 6e-3
+
+
+def test_tile_gemm_exact_integers_catch_a_permuted_store():
+    """A = identity rows, W = asymmetric small integers (exact in bf16): the output must be W^T bit
+    for bit.  A transposed accumulator map, a wrong column order inside the 8-column groups the
+    epilogue writes, or a swizzle mismatch between the load and the fragment reads all fail this."""
+    n = k = 768
+    m = 512
+    x = torch.zeros(m, k, device=DEV)
+    x[torch.arange(m), (torch.arange(m) * 5 + 3) % k] = 1.0
+    w = ((torch.arange(n, device=DEV).view(n, 1) * 3 + torch.arange(k, device=DEV).view(1, k) * 7) % 251).float()
+    got = ops.tile_gemm(x.to(BF), w.to(BF))
+    assert torch.equal(got.float(), x @ w.t())
+
+
+@pytest.mark.parametrize("m,inter,k", [(300, 96, 128), (513, 14336, 256), (2048, 1024, 4096)])
+def test_tile_gemm_swiglu_epilogue(m, inter, k):
+    torch.manual_seed(42)
+    x = (torch.rand(m, k, device=DEV) * 2 - 1).to(BF)
+    w = ((torch.rand(2 * inter, k, device=DEV) * 2 - 1) * 0.1).to(BF)
+    y = x.float() @ w.float().t()
+    ref = torch.nn.functional.silu(y[:, :inter]) * y[:, inter:]
+    assert _rel(ops.tile_gemm(x, w, silu_mul=True), ref) < 8e-3
+
+
+def test_tile_gemm_grouped_with_gather():
+    """Device-side problem list: empty and one-row groups, gathered input rows, rows past the last
+    group untouched."""
+    torch.manual_seed(43)
+    g, n, k, t = 6, 520, 256, 1500
+    counts = [0, 300, 1, 899, 0, 257]
+    rows = sum(counts)
+    x = (torch.rand(t, k, device=DEV) * 2 - 1).to(BF)
+    w = ((torch.rand(g, n, k, device=DEV) * 2 - 1) * 0.1).to(BF)
+    off = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int32, device=DEV)
+    idx = torch.randint(0, t, (rows + 9,), dtype=torch.int32, device=DEV)
+    out = torch.full((rows + 9, n), 7.0, dtype=BF, device=DEV)
+    ops.tile_gemm(x, w, offsets=off, rows=rows + 9, arow_idx=idx, out=out)
+    lo = 0
+    for gi, cnt in enumerate(counts):
+        if cnt:
+            exp = x[idx[lo:lo + cnt].long()].float() @ w[gi].float().t()
+            assert _rel(out[lo:lo + cnt], exp) < 6e-3, gi
+        lo += cnt
+    assert (out[rows:] == 7.0).all()
+
+
+def test_projection_ops_route_prefill_batches_to_the_tile_kernel():
+    """``linear`` / ``linear_add`` / ``gate_up_silu`` on a prefill-sized batch whose tiles fill the
+    chip go through the hand-written kernel (ragged last row tile included) and equal the fp32
+    definition; small batches and half-empty tile rounds stay on the other paths."""
+    torch.manual_seed(44)
+    m, k, n = 4096 - 37, 512, 4096
+    x = (torch.rand(m, k, device=DEV) * 2 - 1).to(BF)
+    w = ((torch.rand(n, k, device=DEV) * 2 - 1) * 0.1).to(BF)
+    assert ops.tile_rows(x, w) == m
+    assert ops.tile_rows(x[:4096 - 256 * 3], w) == 0, "13 x 16 tiles leave the chip's only round a fifth empty"
+    assert ops.tile_rows(x[:300], w) == 0, "small batches stay on the streaming / library path"
+    ref = x.float() @ w.float().t()
+    assert _rel(ops.linear(x, w), ref) < 6e-3
+    b = (torch.rand(n, device=DEV) * 2 - 1).to(BF)
+    assert _rel(ops.linear(x, w, b), ref + b.float()) < 6e-3
+    res = (torch.rand(m, n, device=DEV) * 2 - 1).to(BF)
+    want = ref + res.float()
+    assert ops.linear_add(x, w, res) is None
+    assert _rel(res, want) < 6e-3
+    inter = n // 2
+    want = torch.nn.functional.silu(ref[:, :inter]) * ref[:, inter:]
+    assert _rel(ops.gate_up_silu(x, w), want) < 8e-3
+    old = ops.set_tile_gemm(False)
+    try:
+        assert ops.tile_rows(x, w) == 0
+        h = ops.linear_add(x, w, res)
+        assert h is not None and _rel(h, ref) < 6e-3
+    finally:
+        ops.set_tile_gemm(old)
+
+
 @pytest.mark.parametrize("t,hidden,inter,skew", [
     (300, 512, 1024, False), (1024, 512, 1024, True), (4096, 4096, 14336, False)])
 def test_moe_prefill_grouped_gemm_experts(t, hidden, inter, skew):

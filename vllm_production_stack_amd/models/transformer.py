@@ -218,14 +218,13 @@ class TransformerModel:
             act = ops.silu_and_mul(gu.view(e * t, -1)).view(e, t, -1)
             y = torch.matmul(act, lw.w2.transpose(1, 2))  # [E, T, H]
             return (y.float() * dense.t().unsqueeze(-1)).sum(0).to(x.dtype)
-        if (x.is_cuda and t <= ops.MOE_GROUPED_MAX_TOKENS
-                and ops.grouped_gemm_supported(2 * lw.w2.shape[2], x.shape[1], True)
+        if (x.is_cuda and ops.grouped_gemm_supported(2 * lw.w2.shape[2], x.shape[1], True)
                 and ops.grouped_gemm_supported(x.shape[1], lw.w2.shape[2])):
-            # Prefill chunks up to a few thousand tokens: two grouped matrix-core GEMMs over the
-            # device-sorted (token, expert) pairs.  The host never reads the per-expert counts, so
-            # it keeps launching ahead of the GPU.
+            # Prefill chunks of any size: two grouped matrix-core GEMMs over the device-sorted
+            # (token, expert) pairs (gate_up gathers its rows and fuses SwiGLU).  The host never reads
+            # the per-expert counts, so it keeps launching ahead of the GPU.
             return ops.moe_experts_prefill(x, lw.w13, lw.w2, ids, w)
-        # Whole 8k-token chunks: per-expert library GEMMs (row ranges needed on the host)
+        # The CPU, and shapes the grouped kernel does not tile: per-expert products on the sorted rows
         offsets, pos, sorted_tok = ops.moe_align(ids, e)
         xs = ops.moe_permute(x, sorted_tok)
         off = offsets.tolist()
@@ -236,6 +235,19 @@ class TransformerModel:
                 gu = F.linear(xs[a:b], lw.w13[ex])
                 torch.matmul(ops.silu_and_mul(gu), lw.w2[ex].t(), out=ys[a:b])  # no staging copy
         return ops.moe_combine(ys, w, pos, t)
+
+    def _out_proj(self, name: str, layer: int, x: torch.Tensor, w: torch.Tensor, packed, residual: torch.Tensor,
+                  meta: BatchMeta):
+        """An output projection (o, down) and its all-reduce.  Single-rank replicas let the prefill
+        GEMM add the product straight into the residual stream (its epilogue) and return None;
+        otherwise the product comes back for the fused add + norm kernel."""
+        if self.tp_size == 1:
+            h = ops.linear_add(x, w, residual, packed)
+            if h is None:
+                self._lora(name, layer, x, residual, meta)  # an adapter's delta lands in the stream as well
+                return None
+            return self._lora(name, layer, x, h, meta)
+        return tp_all_reduce(self._lora(name, layer, x, ops.linear(x, w, None, packed), meta))
 
     def _lora(self, name: str, layer: int, x: torch.Tensor, y: torch.Tensor, meta: BatchMeta):
         if self.lora is not None and meta.lora_slots is not None:
@@ -260,13 +272,14 @@ class TransformerModel:
             if residual is None:
                 residual = h
                 x = ops.rms_norm(h, lw.ln1, cfg.norm_eps)
+            elif h is None:  # the previous projection's epilogue already updated the residual stream
+                x = ops.rms_norm(residual, lw.ln1, cfg.norm_eps)
             else:
                 x = ops.rms_norm(h, lw.ln1, cfg.norm_eps, residual)
             qkv = self._lora("qkv", gl, x, ops.qkv_linear(x, lw.wqkv, lw.bqkv, self.n_q * self.head_dim), meta)
             attn = self._attention(qkv, pool, li, meta)
-            h = self._lora("o", gl, attn, ops.linear(attn, lw.wo), meta)
-            h = tp_all_reduce(h)
-            x = ops.rms_norm(h, lw.ln2, cfg.norm_eps, residual)
+            h = self._out_proj("o", gl, attn, lw.wo, None, residual, meta)
+            x = ops.rms_norm(residual, lw.ln2, cfg.norm_eps) if h is None else ops.rms_norm(h, lw.ln2, cfg.norm_eps, residual)
             if cfg.num_experts > 0:
                 h = self._moe(x, lw, decode_only)
             else:
@@ -275,16 +288,20 @@ class TransformerModel:
                     act = ops.silu_and_mul(gu)
                 else:
                     act = ops.gate_up_silu(x, lw.w_gate_up, lw.w_gate_up_p if decode_only else None)
-                h = self._lora("down", gl, act,
-                               ops.linear(act, lw.w_down, None, lw.w_down_p if decode_only else None), meta)
-            h = tp_all_reduce(h)
+                h = self._out_proj("down", gl, act, lw.w_down, lw.w_down_p if decode_only else None, residual, meta)
+            if cfg.num_experts > 0:
+                h = tp_all_reduce(h)
         if not pp.is_last:
+            if h is None:  # the last projection added itself into the residual stream
+                h = torch.zeros_like(residual)
             pp_send(h, pp.next)
             pp_send(residual, pp.next)
             return None
         if meta.logits_rows is not None:
-            h = h.index_select(0, meta.logits_rows)
+            h = None if h is None else h.index_select(0, meta.logits_rows)
             residual = residual.index_select(0, meta.logits_rows)
+        if h is None:
+            return ops.rms_norm(residual, self.norm, cfg.norm_eps)
         return ops.rms_norm(h, self.norm, cfg.norm_eps, residual)
 
     def compute_logits(self, hidden: torch.Tensor) -> torch.Tensor:

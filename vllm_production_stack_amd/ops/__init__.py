@@ -36,7 +36,7 @@ def _kernels():
             "vpsa_stream_gemm_splits", "vpsa_set_stream_targets", "vpsa_rans_encode", "vpsa_rans_pack",
             "vpsa_rans_decode", "vpsa_sample", "vpsa_grouped_gemm", "vpsa_packed_gemm",
             "vpsa_packed_gemm_splits", "vpsa_set_packed_target", "vpsa_dense_decode_attention", "vpsa_dense_attention",
-            "vpsa_tile_gemm",
+            "vpsa_tile_gemm", "vpsa_tile_gemm_debug",
         ):
             getattr(lib, name).restype = c_int
         if os.environ.get("VPSA_PREFILL_VARIANT"):  # pin one prefill kernel for A/B runs
@@ -492,11 +492,59 @@ DIRECT_MAX_WEIGHT_ELEMS = 4096 * 4096
 STREAM_MAX_K = 8192
 
 
+# The prefill GEMM (``tile_gemm``: 256 x 256 tiles, one workgroup per CU) is used when its tiles fill
+# the chip's 256 CUs in whole rounds: measured on MI355X against the library at 8192 rows 0.95-0.98x
+# plain, 1.08x with the SwiGLU epilogue fused (profiles/r3_tile_gemm_micro_v1.jsonl); with the last
+# round of tiles half empty (e.g. 4096 x 4096 at 4616 rows: 304 tiles = 1.19 rounds) the library's
+# stream-K decomposition wins, and below ~1k rows every 256-row tile is mostly padding.
+TILE_MIN_ROWS = int(os.environ.get("VPSA_TILE_MIN_ROWS", "1024"))
+TILE_MIN_FILL = float(os.environ.get("VPSA_TILE_MIN_FILL", "0.85"))
+TILE_CUS = 256
+_tile_enabled = os.environ.get("VPSA_TILE_GEMM", "1") != "0"
+
+
+def set_tile_gemm(on: bool) -> bool:
+    """Switch the hand-written prefill GEMM on or off (A/B timing); returns the old value."""
+    global _tile_enabled
+    old, _tile_enabled = _tile_enabled, bool(on)
+    return old
+
+
+_shape_log = {} if os.environ.get("VPSA_SHAPE_LOG") else None
+if _shape_log is not None:
+    import atexit
+    import sys
+    atexit.register(lambda: print("VPSA_SHAPE_LOG", sorted(_shape_log.items(), key=lambda kv: -kv[1])[:60], file=sys.stderr, flush=True))
+
+
+def tile_rows(x, w, pair: bool = False) -> int:
+    """How many leading rows of ``x`` the prefill GEMM should take for ``x @ w.T``: all of them
+    (a ragged last row tile is handled inside the kernel; a separate small GEMM for the remainder
+    costs more than the padding), or 0 when the library is the better choice for this shape."""
+    if not (_tile_enabled and x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+            and w.dim() == 2 and w.is_contiguous() and x.stride(1) == 1 and x.stride(0) % 8 == 0):
+        return 0
+    m, (n, k) = x.shape[0], w.shape
+    if _shape_log is not None:
+        _shape_log[(m, n, k)] = _shape_log.get((m, n, k), 0) + 1
+    if m < TILE_MIN_ROWS or not tile_gemm_supported(n, k, pair):
+        return 0
+    m_tiles = (m + 255) // 256
+    n_tiles = (n // 2 + 127) // 128 if pair else (n + 255) // 256
+    tiles = m_tiles * n_tiles
+    rounds = (tiles + TILE_CUS - 1) // TILE_CUS
+    if tiles / (rounds * TILE_CUS) < TILE_MIN_FILL:
+        return 0
+    return m
+
+
 def linear(x, w, bias=None, packed=None):
-    """y = x @ w.T (+ bias).  Decode batches of up to 16 rows run the weight-streaming MFMA
-    kernels of ``csrc/kernels/gemm.hip`` (which one depends on the weight's shape); everything
-    else goes to the library GEMM (hipBLASLt).  ``packed``: ``pack_weight(w)`` when the caller
-    keeps one (decode-only steps): up to 64 rows then stream that copy."""
+    """y = x @ w.T (+ bias).  Prefill-sized batches run the hand-written 256 x 256 MFMA kernel
+    (``csrc/kernels/tile_gemm.hip``) when its tiles fill the chip; decode batches of up to 16 rows
+    the weight-streaming MFMA kernels of ``csrc/kernels/gemm.hip`` (which one depends on the
+    weight's shape); everything else goes to the library GEMM (hipBLASLt).  ``packed``:
+    ``pack_weight(w)`` when the caller keeps one (decode-only steps): up to 64 rows then stream
+    that copy."""
     if packed is not None and x.dim() == 2 and x.shape[0] <= PACKED_MAX_ROWS and _skinny_ok(x, w, bias):
         y = packed_linear(x, packed, w.shape[0], w.shape[1], bias, False)
         if y is not None:
@@ -509,7 +557,29 @@ def linear(x, w, bias=None, packed=None):
             y = _stream_gemm(x, w, bias, False)
         if y is not None:
             return y
+    rows = tile_rows(x, w) if (bias is None or bias.dtype == torch.bfloat16) else 0
+    if rows:
+        m = x.shape[0]
+        out = torch.empty((m, w.shape[0]), dtype=x.dtype, device=x.device)
+        # a bias is a "residual" with row stride 0
+        tile_gemm(x[:rows], w, residual=None if bias is None else bias.view(1, -1).expand(rows, -1), out=out[:rows])
+        if rows < m:
+            out[rows:] = linear(x[rows:], w, bias)
+        return out
     return torch.nn.functional.linear(x, w, bias)
+
+
+def linear_add(x, w, residual, packed=None):
+    """The residual-stream update of an output projection: ``residual += x @ w.T`` inside the GEMM's
+    epilogue when the prefill kernel takes the shape (returns None: nothing is left to add), else
+    returns ``x @ w.T`` for the caller's fused add + norm."""
+    rows = tile_rows(x, w) if residual.is_contiguous() else 0
+    if not rows:
+        return linear(x, w, None, packed)
+    tile_gemm(x[:rows], w, residual=residual[:rows], out=residual[:rows])
+    if rows < x.shape[0]:
+        residual[rows:] += linear(x[rows:], w)
+    return None
 
 
 # The library's pick for the fused q/k/v width of Llama-3-8B (6144 columns) is 12-14 % slower per
@@ -519,11 +589,11 @@ SPLIT_QKV_MIN_ROWS = 4096
 
 
 def qkv_linear(x, w, bias, q_cols: int):
-    """The fused q/k/v projection.  Prefill-sized batches without a bias issue it as two library
-    GEMMs, [q | k v], each writing its column range of ONE output buffer (same bits as the single
-    call); everything else is ``linear``."""
+    """The fused q/k/v projection: ``linear``, except that prefill-sized batches which the
+    hand-written kernel does not take and that have no bias go to the library as two GEMMs,
+    [q | k v], each writing its column range of ONE output buffer (same bits as the single call)."""
     if (bias is None and x.is_cuda and x.dim() == 2 and x.shape[0] >= SPLIT_QKV_MIN_ROWS
-            and x.dtype == torch.bfloat16 and 0 < q_cols < w.shape[0]):
+            and x.dtype == torch.bfloat16 and 0 < q_cols < w.shape[0] and not tile_rows(x, w)):
         out = torch.empty((x.shape[0], w.shape[0]), dtype=x.dtype, device=x.device)
         torch.matmul(x, w[:q_cols].t(), out=out[:, :q_cols])
         torch.matmul(x, w[q_cols:].t(), out=out[:, q_cols:])
@@ -532,8 +602,9 @@ def qkv_linear(x, w, bias, q_cols: int):
 
 
 def gate_up_silu(x, w_gate_up, packed=None):
-    """silu(x @ Wg.T) * (x @ Wu.T) for ``w_gate_up = [Wg; Wu]``: fused in one kernel for
-    decode batches, library GEMM + activation kernel otherwise.  ``packed`` as in ``linear``."""
+    """silu(x @ Wg.T) * (x @ Wu.T) for ``w_gate_up = [Wg; Wu]``: fused in one kernel for decode
+    batches (weight-streaming kernels) and for prefill batches (SwiGLU epilogue of the 256 x 256
+    MFMA kernel); library GEMM + activation kernel for what neither takes.  ``packed`` as in ``linear``."""
     if packed is not None and x.dim() == 2 and x.shape[0] <= PACKED_MAX_ROWS and _skinny_ok(x, w_gate_up, None):
         y = packed_linear(x, packed, w_gate_up.shape[0], w_gate_up.shape[1], None, True)
         if y is not None:
@@ -544,6 +615,14 @@ def gate_up_silu(x, w_gate_up, packed=None):
             y = _skinny(x, w_gate_up, None, True)
         if y is not None:
             return y
+    rows = tile_rows(x, w_gate_up, True)
+    if rows:
+        m = x.shape[0]
+        out = torch.empty((m, w_gate_up.shape[0] // 2), dtype=x.dtype, device=x.device)
+        tile_gemm(x[:rows], w_gate_up, silu_mul=True, out=out[:rows])
+        if rows < m:
+            silu_and_mul(torch.nn.functional.linear(x[rows:], w_gate_up), out=out[rows:])
+        return out
     return silu_and_mul(torch.nn.functional.linear(x, w_gate_up))
 
 
@@ -905,15 +984,6 @@ def tile_gemm(a, w, offsets=None, rows=None, arow_idx=None, silu_mul=False, resi
     return out
 
 
-# Prefill-sized MoE batches up to this many tokens run two grouped GEMMs over all experts (one
-# launch each, problem sizes read on the device); larger ones a library GEMM per expert, which needs
-# the per-expert row counts on the host.  Measured on one Mixtral-8x7B layer (MI355X, ms per layer,
-# grouped / per-expert): 512 tokens 0.81 / 1.01, 1024 1.10 / 1.33, 2048 1.72 / 1.97, 4096 2.90 / 3.02,
-# 8192 5.37 / 5.12: below ~4k tokens the per-expert GEMMs are too small to fill the chip and their 16
-# launches and the host round trip show; at 8k the library's kernel is the faster one.
-MOE_GROUPED_MAX_TOKENS = int(os.environ.get("VPSA_MOE_GROUPED_MAX_TOKENS", "4096"))
-
-
 def grouped_gemm_supported(n: int, k: int, silu_mul: bool = False) -> bool:
     return k % 64 == 0 and (not silu_mul or (n // 2) % 32 == 0)
 
@@ -928,11 +998,13 @@ def moe_experts_prefill(x, w13, w2, ids, weights, gather=True):
         return reference.moe_experts(x, w13, w2, ids, weights)
     n_experts = w13.shape[0]
     offsets, pos, sorted_tok = moe_align(ids, n_experts)
+    gg = tile_gemm if (tile_gemm_supported(w13.shape[1], w13.shape[2], True)
+                       and tile_gemm_supported(w2.shape[1], w2.shape[2])) else grouped_gemm
     if gather:
-        act = grouped_gemm(x, w13, offsets, rows=t * k, arow_idx=sorted_tok, silu_mul=True)
+        act = gg(x, w13, offsets, rows=t * k, arow_idx=sorted_tok, silu_mul=True)
     else:  # copy the rows into sorted order first (timing comparison)
-        act = grouped_gemm(moe_permute(x, sorted_tok), w13, offsets, rows=t * k, silu_mul=True)
-    y = grouped_gemm(act, w2, offsets, rows=t * k)
+        act = gg(moe_permute(x, sorted_tok), w13, offsets, rows=t * k, silu_mul=True)
+    y = gg(act, w2, offsets, rows=t * k)
     return moe_combine(y, weights, pos, t)
 
 
