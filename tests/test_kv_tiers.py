@@ -378,3 +378,59 @@ def test_prefix_caching_off_with_host_tier_serves_every_turn_from_host():
         assert r.num_cached_tokens == 0 and r.num_external_tokens == 320
     assert eng.connector.host.loads >= 10
     eng.shutdown()
+
+
+def test_staged_download_returns_its_slots_when_the_connection_dies_half_way():
+    """Bulk download of raw pages through the pinned staging ring: a cache server that stops
+    answering after k pages must not cost the ring a single slot (a leaked slot per hiccup would
+    end with the engine thread blocked on an empty ring), and a ring that stays empty makes the
+    download fall back to the per-page path instead of waiting for ever."""
+    import queue
+
+    import torch
+
+    from vllm_production_stack_amd.kv.connector import KVConnector
+
+    elems, n_slots = 64, 4
+
+    class Serde:
+        page_elems = elems
+
+        def _header(self, n):
+            return b"HDR" + int(n).to_bytes(4, "little")
+
+    class Remote:
+        def __init__(self, die_after):
+            self.calls, self.die_after = 0, die_after
+
+        def get_page_into(self, key, hdr_len, view):
+            self.calls += 1
+            if self.calls > self.die_after:
+                raise ConnectionError("server went away")
+            view[:] = bytes([self.calls]) * len(view)
+            return Serde()._header(elems * 2)
+
+    c = object.__new__(KVConnector)
+    c.device = torch.device("cpu")
+    c.serde = Serde()
+    c._stage = torch.zeros((n_slots, elems), dtype=torch.bfloat16)
+    c._stage_free = queue.Queue()
+    for i in range(n_slots):
+        c._stage_free.put(i)
+    c.pool = torch.zeros((16, elems), dtype=torch.bfloat16)
+    c._key = lambda h: f"k{h}"
+    c.remote = Remote(die_after=6)  # more pages than slots: the ring is recycled once, then the link dies
+    items = [(100 + i, i) for i in range(10)]
+    with pytest.raises(ConnectionError):
+        c._download_staged(items)
+    assert c._stage_free.qsize() == n_slots
+    # pages that did arrive are in the pool
+    assert bool((c.pool[0].view(torch.uint8) == 1).all()) and bool((c.pool[5].view(torch.uint8) == 6).all())
+    # an exhausted ring (uploads hold every slot): the rest is handed to the per-page path
+    held = [c._stage_free.get() for _ in range(n_slots)]
+    c.remote = Remote(die_after=100)
+    c.STAGE_WAIT_S = 0.05
+    assert c._download_staged(items[:3]) == items[:3]
+    for sl in held:
+        c._stage_free.put(sl)
+    assert c._download_staged(items[:3]) == [] and c._stage_free.qsize() == n_slots

@@ -145,12 +145,72 @@ def test_a_timed_out_one_shot_all_reduce_fails_the_step_and_falls_back():
         state.check_collectives()  # healthy: nothing happens
         assert tp.oneshot is stub
         stub.bad = True
-        with pytest.raises(RuntimeError, match="all-reduce timed out"):
+        with pytest.raises(state.CollectiveError, match="all-reduce timed out"):
             state.check_collectives()
-        assert tp.oneshot is None and stub.closed
-        state.check_collectives()  # and the next step runs (over RCCL)
+        # nothing is unmapped: captured graphs and polling peers may still touch the buffers
+        assert tp.oneshot is stub and not stub.closed and tp.failed
+        stub.bad = False
+        with pytest.raises(state.CollectiveError):  # the replica stays failed: one more step fails the same way
+            state.check_collectives()
     finally:
         tp.oneshot = old
+        tp.failed = False
+
+
+def test_a_failed_collective_stops_the_engine_thread_for_good():
+    """An injected all-reduce time-out during a step: in-flight requests get the error, the engine
+    thread takes no further step (a step after the failure would replay graphs whose ranks have
+    diverged), the replica reports unhealthy for good and refuses new work."""
+    import asyncio
+
+    from vllm_production_stack_amd.engine.async_engine import AsyncLLMEngine
+    from vllm_production_stack_amd.parallel import state
+
+    class Eng:
+        device = None
+        is_sleeping = False
+        requests: dict = {}
+
+        def __init__(self):
+            self.steps = 0
+            self.work = False
+
+        def add_request(self, ids, params, rid, lora, kvp, pooling):
+            self.work = True
+            return object()
+
+        def has_work(self):
+            return self.work
+
+        def step(self):
+            self.steps += 1
+            raise state.CollectiveError("tensor-parallel all-reduce timed out waiting for a peer rank")
+
+        def abort(self, rid):
+            pass
+
+        def idle_tick(self):
+            pass
+
+        def shutdown(self):
+            pass
+
+    async def go():
+        eng = Eng()
+        ae = AsyncLLMEngine(eng)
+        ae.start(asyncio.get_running_loop())
+        with pytest.raises(RuntimeError, match="timed out"):
+            async for _ in ae.generate("r1", [1, 2, 3], None):
+                pass
+        await asyncio.sleep(0.3)
+        assert eng.steps == 1, "no step after the failed one"
+        assert not ae.healthy and ae.fatal is not None
+        with pytest.raises(RuntimeError, match="replica failed"):
+            async for _ in ae.generate("r2", [1], None):
+                pass
+        ae.stop()
+
+    asyncio.run(go())
 
 
 def test_decode_plan_travels_as_integers_and_back():

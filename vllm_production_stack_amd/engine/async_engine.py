@@ -33,6 +33,7 @@ class AsyncLLMEngine:
         self._errors: dict[str, Exception] = {}
         self._live: dict[str, object] = {}  # request id -> Request (for pooled results)
         self.healthy = True
+        self.fatal: Exception | None = None  # set when the engine thread has given up (see _run)
         self._control_lock = threading.Lock()
 
     def start(self, loop: asyncio.AbstractEventLoop | None = None) -> None:
@@ -102,6 +103,12 @@ class AsyncLLMEngine:
                         eng.abort(rid)
                     except Exception:
                         pass
+                if type(e).__name__ == "CollectiveError":
+                    # the ranks of this replica no longer agree on where they are: no more steps;
+                    # /health answers 503 from now on and the supervisor restarts the replica
+                    self.fatal = e
+                    log.error("replica failed for good: %s", e)
+                    return
                 time.sleep(0.1)
                 self.healthy = True
 
@@ -109,6 +116,8 @@ class AsyncLLMEngine:
     async def generate(self, request_id: str, prompt_ids: list[int], params: SamplingParams,
                        lora_name: str | None = None, kv_transfer_params: dict | None = None,
                        pooling: bool = False) -> AsyncIterator[StepOutput]:
+        if self.fatal is not None:  # the engine thread has ended: nothing would ever answer
+            raise RuntimeError(f"engine replica failed: {self.fatal}")
         q: asyncio.Queue = asyncio.Queue()
         self._queues[request_id] = q
         self._inbox.append(("add", (request_id, prompt_ids, params, lora_name, kv_transfer_params, pooling)))

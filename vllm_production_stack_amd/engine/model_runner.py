@@ -325,10 +325,13 @@ class ModelRunner:
 
     @staticmethod
     def _check_worker_collectives() -> None:
+        """Lags a step on worker ranks (they never read back).  A failed collective ends the worker
+        loop with the error: the rank's process exits non-zero and the replica is restarted."""
         try:
-            check_collectives()  # lags a step on worker ranks (they never read back)
+            check_collectives()
         except RuntimeError as e:
             log.error("%s", e)
+            raise
 
     def stop_workers(self) -> None:
         if self.distributed and self.replica.is_driver:

@@ -209,6 +209,8 @@ class KVConnector:
                              "serde": "cachegen" if self.serde.kind else "naive"}
         return out
 
+    STAGE_WAIT_S = 2.0  # how long a download waits for a staging slot before it goes page by page
+
     def load_pages(self, hashes: list[int], pages: list[int]):
         """Start loading ``hashes`` into HBM ``pages``.  Returns ``(fence, n_loaded)``: an
         event-like object the runner fences the compute stream on (None when the data is already
@@ -234,26 +236,21 @@ class KVConnector:
                 from_host.append((h, p))
             else:
                 slow.append((h, p))
+        bulk_done: list[tuple[int, int]] = []  # fetched in bulk; copied to the host tier once first_bad is known
         try:
             if self._stage is not None and slow:
                 on_disk = [(h, p) for h, p in slow if self.disk is not None and self.disk.contains(h)]
                 fetched = [(h, p) for h, p in slow if (h, p) not in set(on_disk)]
                 missing = self._download_staged(fetched)
                 self.loaded_from["remote"] += len(fetched) - len(missing)
-                if self.host is not None:
-                    done = [x for x in fetched if x not in set(missing)]
-                    if done:
-                        self.host.store(done)
+                bulk_done = [x for x in fetched if x not in set(missing)]
                 slow = on_disk + missing
             elif self.remote is not None and self.serde.kind != 0 and slow:
                 on_disk = [(h, p) for h, p in slow if self.disk is not None and self.disk.contains(h)]
                 fetched = [x for x in slow if x not in set(on_disk)]
                 missing = self._download_codec(fetched)
                 self.loaded_from["remote"] += len(fetched) - len(missing)
-                if self.host is not None:
-                    done = [x for x in fetched if x not in set(missing)]
-                    if done:
-                        self.host.store(done)
+                bulk_done = [x for x in fetched if x not in set(missing)]
                 slow = on_disk + missing
         except Exception as e:  # connection lost half way: what was not confirmed is looked at one by one
             log.warning("bulk KV download failed: %s", e)
@@ -283,8 +280,12 @@ class KVConnector:
                 continue
             self.loaded_from[src] += 1
             self.pool[p].view(-1).copy_(t.view(-1))
-            if self.host is not None:
-                self.host.store([(h, p)])
+            bulk_done.append((h, p))
+        # Only pages in front of the first missing one stay with the request: the scheduler frees
+        # the others at once and may hand them to somebody else while a copy to the host tier is
+        # still queued, which would file wrong bytes under a valid hash.  The kept pages are
+        # pinned until their copy has landed, like freshly computed ones.
+        self._host_store_pinned([(h, p) for h, p in bulk_done if idx_of[h] < first_bad])
         from_host = [(h, p) for h, p in from_host if idx_of[h] < first_bad]
         ev = self.host.load(from_host) if from_host else None
         self.loaded_from["host"] += len(from_host)
@@ -294,16 +295,23 @@ class KVConnector:
             return None, first_bad
         return _ComputeFence(self.host, ev), first_bad
 
+    def _host_store_pinned(self, pairs: list[tuple[int, int]]) -> None:
+        """Copy (hash, page) pairs to the host tier; the HBM pages keep a reference until the
+        (asynchronous) copy has read them."""
+        if self.host is None or not pairs:
+            return
+        ev = self.host.store(pairs)
+        if ev is not None:
+            pages = [p for _, p in pairs]
+            for p in pages:
+                self.engine.bm.ref[p] += 1
+            self._pending.append((ev, pages))
+
     def store_pages(self, fresh: list[tuple[int, int]]) -> None:
         """Write-through of newly filled pages (hash, page)."""
         t0 = time.time()
         if self.host is not None:
-            ev = self.host.store(fresh)
-            if ev is not None:
-                pages = [p for _, p in fresh]
-                for p in pages:  # keep the HBM pages alive until the copy has landed
-                    self.engine.bm.ref[p] += 1
-                self._pending.append((ev, pages))
+            self._host_store_pinned(fresh)
             self.metrics.kv_local_usage.set(self.host.used_bytes())
             self.metrics.cpu_cache_usage.set(len(self.host.index) / self.host.n_slots)
         if self.remote is not None and self._stage is not None:
@@ -424,29 +432,42 @@ class KVConnector:
         left: list[tuple[int, int]] = []
         hdr_len = len(self.serde._header(0))
         want = self.serde._header(self.serde.page_elems * self._stage.element_size())
-        stream = torch.cuda.current_stream(self.device)
+        stream = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else _NoStream()
         used: list[int] = []
-        for h, p in items:
-            try:
-                slot = self._stage_free.get_nowait()
-            except queue.Empty:
-                stream.synchronize()  # the copies out of the slots taken so far have landed
+        slot = None
+        try:
+            for i, (h, p) in enumerate(items):
+                try:
+                    slot = self._stage_free.get_nowait()
+                except queue.Empty:
+                    stream.synchronize()  # the copies out of the slots taken so far have landed
+                    for sl in used:
+                        self._stage_free.put(sl)
+                    used = []
+                    try:  # uploads hold the rest of the ring: wait a little, then take the per-page path
+                        slot = self._stage_free.get(timeout=self.STAGE_WAIT_S)
+                    except queue.Empty:
+                        left.extend(items[i:])
+                        break
+                view = memoryview(self._stage[slot].view(torch.uint8).numpy())
+                hdr = self.remote.get_page_into(self._key(h), hdr_len, view)
+                if hdr != want:
+                    self._stage_free.put(slot)
+                    slot = None
+                    left.append((h, p))
+                    continue
+                self.pool[p].view(-1).copy_(self._stage[slot], non_blocking=True)
+                used.append(slot)
+                slot = None
+        finally:
+            # also on a connection lost half way: every slot goes back to the ring, once the copies
+            # that read them have landed
+            if used:
+                stream.synchronize()
                 for sl in used:
                     self._stage_free.put(sl)
-                used = []
-                slot = self._stage_free.get()
-            view = memoryview(self._stage[slot].view(torch.uint8).numpy())
-            hdr = self.remote.get_page_into(self._key(h), hdr_len, view)
-            if hdr != want:
+            if slot is not None:
                 self._stage_free.put(slot)
-                left.append((h, p))
-                continue
-            self.pool[p].view(-1).copy_(self._stage[slot], non_blocking=True)
-            used.append(slot)
-        if used:
-            stream.synchronize()
-            for sl in used:
-                self._stage_free.put(sl)
         return left
 
     def poll(self) -> None:
@@ -540,6 +561,13 @@ class KVConnector:
             self.host.close()
         if self.remote is not None:
             self.remote.close()
+
+
+class _NoStream:
+    """Stands in for the compute stream where copies are synchronous (host-only runs)."""
+
+    def synchronize(self) -> None:
+        pass
 
 
 class _TorchEvent:

@@ -31,6 +31,7 @@ class TPGroup:
     group: "dist.ProcessGroup | None" = None
     cpu_group: "dist.ProcessGroup | None" = None  # gloo side channel for control messages
     oneshot: object = None  # OneShotAllReduce when enabled (small bf16 all-reduces)
+    failed: bool = False  # a one-shot collective timed out: this replica has to be restarted
     host_staged: "bool | None" = None  # GPU operands over a gloo group (one-card rehearsal)
 
     @property
@@ -176,20 +177,25 @@ def enable_oneshot_all_reduce(device: torch.device, max_bytes: int = 4 << 20,
     return True
 
 
+class CollectiveError(RuntimeError):
+    """A collective of this replica gave up waiting for a peer: the replica cannot go on."""
+
+
 def check_collectives() -> None:
     """Once per engine step, after the step's read-back: did a one-shot all-reduce of the steps
     finished so far give up waiting for a peer?  Its operand was then left unreduced, so what
-    was sampled from it is garbage: fail the step, and stop using the one-shot kernel so that
-    the following steps go through RCCL (the peers follow when their own waits time out)."""
+    was sampled from it is garbage, and the ranks no longer agree on where they are.  The replica
+    is marked failed for good and the error is raised on this and on every later call: the engine
+    stops stepping and reports unhealthy, worker ranks leave their loop, and whatever supervises
+    the replica (torchrun, the pod's liveness probe) restarts it as fresh processes.  Nothing is
+    unmapped or freed here: the captured decode graphs of this rank still hold launches of the
+    one-shot kernels with these buffers, and a peer's kernel may still be polling them; the
+    mappings go away with the process."""
     tp = _TP
-    if tp.oneshot is not None and tp.oneshot.failed_nosync():
-        one, tp.oneshot = tp.oneshot, None
-        try:
-            one.close()
-        except Exception:
-            pass
-        raise RuntimeError("tensor-parallel all-reduce timed out waiting for a peer rank; "
-                           "one-shot all-reduce disabled, falling back to RCCL")
+    if tp.failed or (tp.oneshot is not None and tp.oneshot.failed_nosync()):
+        tp.failed = True
+        raise CollectiveError("tensor-parallel all-reduce timed out waiting for a peer rank; "
+                              "the replica is marked failed and must be restarted")
 
 
 def _host_staged(tp: TPGroup) -> bool:
