@@ -91,7 +91,8 @@ def _pin_moe_routing(monkeypatch):
         e1 = tok % e
         e2 = (e1 + 1 + (tok // e) % (e - 1)) % e
         ids = torch.stack([e1, e2], dim=1).to(torch.int32)
-        w = torch.tensor([0.625, 0.375], dtype=torch.float32, device=logits.device).expand(tok.shape[0], 2).contiguous()
+        w = torch.stack([torch.full_like(e1, 0.625, dtype=torch.float32),
+                         torch.full_like(e1, 0.375, dtype=torch.float32)], dim=1)  # fills: graph-capturable
         return w, ids
 
     monkeypatch.setattr(TransformerModel, "forward", forward)
