@@ -118,3 +118,70 @@ def test_kvaware_stays_single_process():
     assert workers.effective_workers(A) == 1
     A.routing_logic = "session"
     assert workers.effective_workers(A) == 4
+
+
+def _metric(text: str, name: str) -> dict:
+    """{server label: value} of one gauge in a Prometheus text page."""
+    out = {}
+    for line in text.splitlines():
+        if line.startswith(name + "{"):
+            labels, val = line[len(name):].rsplit(" ", 1)
+            server = labels.split('server="')[1].split('"')[0] if 'server="' in labels else ""
+            out[server] = float(val)
+    return out
+
+
+def test_a_scrape_of_any_worker_reports_the_whole_router():
+    """Four workers, 200 requests in ten seconds: the kernel spreads the connections over the
+    workers, so every worker saw about a quarter of the traffic, and every single ``/metrics``
+    answer (whichever worker gives it) must report the whole: request rate within 5 % of what the
+    client sent, and the same figure from scrape to scrape."""
+    async def body(url, engines):
+        n, spacing = 200, 0.02
+        t0 = time.time()
+
+        async def one(i):
+            await asyncio.sleep(i * spacing)
+            return await _chat(url, f"question {i}")
+
+        assert set(await asyncio.gather(*[one(i) for i in range(n)])) == {200}
+        sent_for = time.time() - t0
+        await asyncio.sleep(1.2)  # every worker has published its snapshot since the last request
+        pages = []
+        for _ in range(12):  # a connection each: different workers answer
+            async with aiohttp.ClientSession(connector=aiohttp.TCPConnector(force_close=True)) as s:
+                async with s.get(url + "/metrics") as r:
+                    assert r.status == 200
+                    pages.append(await r.text())
+        window = 60.0  # the router's default request-stats window: all 200 requests are inside it
+        want_qps = n / window
+        totals = [sum(_metric(p, "vllm:current_qps").values()) for p in pages]
+        for t in totals:
+            assert abs(t - want_qps) / want_qps < 0.05, (totals, want_qps, sent_for)
+        assert all(sum(_metric(p, "vllm:num_prefill_requests").values()) == 0 for p in pages)
+        lat = [v for p in pages for v in _metric(p, "vllm:avg_latency").values()]
+        assert lat and all(0 < v < 5 for v in lat), lat
+        # the engines together received exactly what the router reports having routed
+        assert sum(len(e.requests) for e in engines) == n
+
+    asyncio.run(_with_router(2, "roundrobin", 4, body))
+
+
+def test_merge_rules_of_worker_snapshots():
+    """Sums for shares of one quantity, request-rate-weighted means for averages, the answering
+    worker's copy for what all workers see alike, -1 (no data) carries no weight."""
+    import msgpack
+
+    from vllm_production_stack_amd.router import metrics
+
+    def snap(qps, lat, running, hits):
+        fam = lambda name, val, typ="gauge": [name, typ, "doc", [[name, {"server": "http://e1"}, val]]]  # noqa: E731
+        return msgpack.packb([fam("vllm:current_qps", qps), fam("vllm:avg_latency", lat),
+                              fam("vllm:num_requests_running", running),
+                              ["vllm_pii_requests", "counter", "doc", [["vllm_pii_requests_total", {}, hits]]]])
+
+    text = metrics.merge_snapshots(1, [(0, snap(3.0, 2.0, 7, 5)), (1, snap(1.0, 6.0, 9, 2)), (2, snap(0.0, -1.0, 9, 0))]).decode()
+    assert _metric(text, "vllm:current_qps") == {"http://e1": 4.0}
+    assert _metric(text, "vllm:avg_latency") == {"http://e1": 3.0}  # (3 * 2 + 1 * 6) / 4
+    assert _metric(text, "vllm:num_requests_running") == {"http://e1": 9.0}  # worker 1 answers
+    assert "vllm_pii_requests_total 7.0" in text

@@ -58,6 +58,7 @@ class RouterState:
         self.semantic_cache_store = None
         self.semantic_cache_check = None
         self.pii_guard = None
+        self.shared_stats = None  # under --router-workers: this worker's client of the supervisor's socket
         self.tasks: list[asyncio.Task] = []
         self.start_time = time.time()
         # request spans go to the collector named by the OTEL_* environment (off without it)
@@ -253,8 +254,29 @@ async def h_health(request):
 
 
 async def h_metrics(request):
-    return web.Response(body=router_metrics.render(_state(request)),
-                        headers={"Content-Type": "text/plain; version=0.0.4; charset=utf-8"})
+    state = _state(request)
+    if state.shared_stats is not None:  # one of several workers answers for the whole router
+        from . import workers
+
+        body = await router_metrics.render_all_workers(state, state.shared_stats, workers.worker_index())
+    else:
+        body = router_metrics.render(state)
+    return web.Response(body=body, headers={"Content-Type": "text/plain; version=0.0.4; charset=utf-8"})
+
+
+async def _publish_stats(state: RouterState, interval: float = 1.0) -> None:
+    """One of several workers: keep this worker's metric snapshot at the supervisor fresh, so that a
+    scrape answered by another worker counts this one's traffic."""
+    from . import workers
+
+    while True:
+        try:
+            await state.shared_stats.put_stats(workers.worker_index(), router_metrics.snapshot(state))
+        except asyncio.CancelledError:
+            raise
+        except Exception as e:
+            logger.debug("publishing the metric snapshot failed: %s", e)
+        await asyncio.sleep(interval)
 
 
 # ---- files ----------------------------------------------------------------------------
@@ -474,6 +496,11 @@ async def initialize_all(state: RouterState) -> None:
     path = args.dynamic_config_yaml or args.dynamic_config_json
     if path:
         state.tasks.append(asyncio.create_task(_dynamic_config_watcher(state, path)))
+    from . import workers as _workers
+
+    if _workers.worker_count() > 1 and _workers.shared_state_path():
+        state.shared_stats = _workers.SharedTrieClient(_workers.shared_state_path())
+        state.tasks.append(asyncio.create_task(_publish_stats(state)))
     if args.log_stats:
         state.tasks.append(asyncio.create_task(_log_stats(state, args.log_stats_interval)))
     gates = initialize_feature_gates(args.feature_gates)
@@ -508,6 +535,8 @@ async def shutdown_all(state: RouterState) -> None:
         await state.engine_stats_scraper.close()
     if state.router is not None:
         await state.router.close()
+    if state.shared_stats is not None:
+        await state.shared_stats.close()
     if state.service_discovery is not None:
         await state.service_discovery.close()
     if state.client is not None:

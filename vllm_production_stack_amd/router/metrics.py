@@ -72,3 +72,113 @@ def refresh(state) -> None:
 def render(state) -> bytes:
     refresh(state)
     return generate_latest(REGISTRY)
+
+
+# ------------------------------------------------------------------ one truth under --router-workers
+# Reference: one process, so one registry is the whole router
+# (/root/reference/src/vllm_router/routers/metrics_router.py:57-123).  With N worker processes a
+# scrape reaches one of them; it answers for all.
+#
+# How a family of one name is merged over the workers' snapshots:
+#   SUMMED    per-worker shares of one quantity: request rates, in-flight counts, cache counters
+#   AVERAGED  per-worker averages of the same population, weighted by the worker's request rate for
+#             that server (a worker that saw no request reports -1 and has no weight)
+#   counters and histograms (type counter / histogram): summed
+#   everything else: what all workers observe alike (engine gauges, pod health, host usage) is
+#             taken from the worker that answers the scrape
+SUMMED = {"vllm:current_qps", "vllm:num_prefill_requests", "vllm:num_decoding_requests",
+          "vllm:num_requests_swapped", "vllm:semantic_cache_hits", "vllm:semantic_cache_misses",
+          "vllm:semantic_cache_size"}
+AVERAGED = {"vllm:avg_latency", "vllm:avg_itl", "vllm:avg_decoding_length", "vllm:semantic_cache_latency"}
+WEIGHT = "vllm:current_qps"
+
+
+def snapshot(state) -> bytes:
+    """This worker's registry as a msgpack blob: [[family, type, doc, [[sample, labels, value], ...]], ...]."""
+    import msgpack
+
+    refresh(state)
+    fams = []
+    for fam in REGISTRY.collect():
+        fams.append([fam.name, fam.type, fam.documentation,
+                     [[s.name, dict(s.labels), float(s.value)] for s in fam.samples]])
+    return msgpack.packb(fams)
+
+
+def merge_snapshots(own: int, blobs: list[tuple[int, bytes]]) -> bytes:
+    """Prometheus text for the whole router from the workers' snapshots; ``own`` is the index of
+    the worker that answers (its copy is used for what is not summed or averaged)."""
+    import msgpack
+    from prometheus_client.core import Metric
+
+    per_worker = {w: msgpack.unpackb(b, raw=False) for w, b in blobs}
+    if own not in per_worker:
+        own = next(iter(per_worker))
+    # request-rate weights: (worker, server) -> qps
+    weight: dict[tuple[int, str], float] = {}
+    for w, fams in per_worker.items():
+        for name, _typ, _doc, samples in fams:
+            if name == WEIGHT:
+                for _sn, labels, v in samples:
+                    weight[(w, labels.get("server", ""))] = max(v, 0.0)
+    order: list[str] = []
+    meta: dict[str, tuple[str, str]] = {}
+    acc: dict[str, dict[tuple, list]] = {}  # family -> (sample name, labels) -> [sum, weight sum]
+    for w, fams in per_worker.items():
+        for name, typ, doc, samples in fams:
+            if name not in meta:
+                meta[name] = (typ, doc)
+                order.append(name)
+                acc[name] = {}
+            summed = name in SUMMED or typ in ("counter", "histogram", "summary")
+            for sn, labels, v in samples:
+                key = (sn, tuple(sorted(labels.items())))
+                if summed:
+                    if sn.endswith("_created"):  # a counter's creation time: the earliest
+                        cur = acc[name].get(key)
+                        acc[name][key] = [v if cur is None else min(cur[0], v), 1.0]
+                    else:
+                        acc[name].setdefault(key, [0.0, 1.0])[0] += v
+                elif name in AVERAGED:
+                    wt = weight.get((w, labels.get("server", "")), 0.0)
+                    slot = acc[name].setdefault(key, [0.0, 0.0])
+                    if v >= 0 and wt > 0:
+                        slot[0] += v * wt
+                        slot[1] += wt
+                elif w == own:
+                    acc[name][key] = [v, 1.0]
+    # the cache's hit ratio follows from the summed hits and misses
+    if "vllm:semantic_cache_hit_ratio" in acc:
+        for key in list(acc["vllm:semantic_cache_hit_ratio"]):
+            lab = key[1]
+            h = acc.get("vllm:semantic_cache_hits", {}).get(("vllm:semantic_cache_hits", lab), [0.0])[0]
+            m = acc.get("vllm:semantic_cache_misses", {}).get(("vllm:semantic_cache_misses", lab), [0.0])[0]
+            acc["vllm:semantic_cache_hit_ratio"][key] = [h / (h + m) if h + m > 0 else 0.0, 1.0]
+
+    class _Merged:
+        def collect(self_inner):
+            for name in order:
+                typ, doc = meta[name]
+                m = Metric(name, doc, typ)
+                for (sn, labels), (num, den) in acc[name].items():
+                    if name in AVERAGED:
+                        val = num / den if den > 0 else -1.0
+                    else:
+                        val = num
+                    m.add_sample(sn, dict(labels), val)
+                yield m
+
+    reg = CollectorRegistry()
+    reg.register(_Merged())
+    return generate_latest(reg)
+
+
+async def render_all_workers(state, client, own: int) -> bytes:
+    """``/metrics`` of one worker of several: publish this worker's fresh snapshot, then merge all."""
+    mine = snapshot(state)
+    try:
+        await client.put_stats(own, mine)
+        blobs = await client.all_stats()
+    except Exception:  # the supervisor is gone or restarting: this worker's own view is better than a 500
+        blobs = [(own, mine)]
+    return merge_snapshots(own, blobs)

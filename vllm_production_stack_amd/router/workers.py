@@ -8,7 +8,15 @@ replicas with tens of users each that relay loop, not a GPU, becomes the first t
 Here N identical router processes listen on the same port (``SO_REUSEPORT``: the kernel spreads
 new connections over them) and each relays the streams of the connections it accepted.  Every
 worker is a complete router (own discovery, own engine-stats scraper, own request statistics);
-what must not be per worker is the routing state that gives a conversation its affinity:
+what must not be per worker is what an observer or a conversation sees as ONE router:
+
+  * ``/metrics``: a scrape lands on one worker chosen by the kernel, and has to report the whole
+    router.  Every worker publishes a snapshot of its metric registry to the supervisor once a
+    second and right before it answers a scrape; the scraped worker merges all snapshots (request
+    rates, in-flight counts and counters are summed, averages are weighted by each worker's
+    request rate, what every worker observes alike (engine gauges, pod health) is reported once):
+    ``router/metrics.py::merge_snapshots``.  The supervisor's unix socket carries both this and
+    the prefix trie;
 
   * the prefix trie of ``prefixaware`` routing lives once, in the supervisor process, behind a
     unix socket (``SharedTrieServer`` / ``SharedTrieClient``): a follow-up turn finds the prefix
@@ -33,6 +41,7 @@ import signal
 import struct
 import tempfile
 import threading
+import time
 
 import msgpack
 
@@ -41,6 +50,7 @@ from .native import HashTrie
 logger = logging.getLogger("vpsa.router.workers")
 
 # set in a worker process before its app is built (see ``worker_main``)
+_shared_state_path: str | None = None  # the supervisor's socket (metric snapshots; the trie when there is one)
 _shared_trie_path: str | None = None
 _shared_rr = None  # multiprocessing.Value('Q') or None
 _worker_index = 0
@@ -63,14 +73,23 @@ def shared_trie_path() -> str | None:
     return _shared_trie_path
 
 
+def shared_state_path() -> str | None:
+    return _shared_state_path
+
+
 # ------------------------------------------------------------------ shared prefix trie
 class SharedTrieServer:
-    """Owns the prefix trie; serves match / insert / forget over a unix socket.  Frames are a
-    4-byte little-endian length followed by a msgpack array."""
+    """The supervisor's shared state behind a unix socket: the prefix trie (match / insert /
+    forget) and the workers' metric snapshots (stats_put / stats_all; a snapshot that has not been
+    refreshed for ``SNAPSHOT_TTL`` seconds belongs to a worker that died and is dropped).  Frames
+    are a 4-byte little-endian length followed by a msgpack array."""
+
+    SNAPSHOT_TTL = 15.0
 
     def __init__(self, path: str, max_nodes: int):
         self.path = path
         self.trie = HashTrie(chunk_size=128, max_nodes=max_nodes)
+        self.snapshots: dict[int, tuple[float, bytes]] = {}  # worker index -> (when, msgpack payload)
         self._loop: asyncio.AbstractEventLoop | None = None
         self._ready = threading.Event()
         self._thread = threading.Thread(target=self._run, name="shared-trie", daemon=True)
@@ -108,6 +127,14 @@ class SharedTrieServer:
                 elif op == "forget":
                     self.trie.remove_endpoint(msg[1])
                     out = [0]
+                elif op == "stats_put":
+                    self.snapshots[int(msg[1])] = (time.time(), msg[2])
+                    out = [0]
+                elif op == "stats_all":
+                    lim = time.time() - self.SNAPSHOT_TTL
+                    for w in [w for w, (t, _) in self.snapshots.items() if t < lim]:
+                        del self.snapshots[w]
+                    out = [0, [[w, blob] for w, (_, blob) in sorted(self.snapshots.items())]]
                 else:
                     out = [-1]
                 body = msgpack.packb(out)
@@ -166,6 +193,13 @@ class SharedTrieClient:
     async def remove_endpoint(self, endpoint: str) -> None:
         await self._call(["forget", endpoint])
 
+    async def put_stats(self, worker: int, snapshot: bytes) -> None:
+        await self._call(["stats_put", worker, snapshot])
+
+    async def all_stats(self) -> list[tuple[int, bytes]]:
+        out = await self._call(["stats_all"])
+        return [(int(w), blob) for w, blob in out[1]]
+
     async def close(self) -> None:
         if self._writer is not None:
             self._writer.close()
@@ -182,9 +216,10 @@ def effective_workers(args) -> int:
     return n
 
 
-def worker_main(args, index: int, count: int, trie_path: str | None, rr) -> None:
-    global _shared_trie_path, _shared_rr, _worker_index, _worker_count
+def worker_main(args, index: int, count: int, trie_path: str | None, rr, state_path: str | None = None) -> None:
+    global _shared_trie_path, _shared_state_path, _shared_rr, _worker_index, _worker_count
     _shared_trie_path, _shared_rr, _worker_index, _worker_count = trie_path, rr, index, count
+    _shared_state_path = state_path or trie_path
     signal.signal(signal.SIGINT, signal.SIG_IGN)  # the supervisor forwards the stop as SIGTERM
     from aiohttp import web
 
@@ -202,17 +237,18 @@ def run_workers(args, n: int) -> None:
     them all on SIGTERM / SIGINT."""
     ctx = multiprocessing.get_context("fork")
     rr = ctx.Value("Q", 0)
-    trie_srv = None
-    trie_path = None
-    if args.routing_logic == "prefixaware":
-        trie_path = os.path.join(tempfile.mkdtemp(prefix="vpsa-router-"), "trie.sock")
-        trie_srv = SharedTrieServer(trie_path, args.prefix_trie_max_nodes)
-        trie_srv.start()
+    # one socket for everything the workers share: metric snapshots always, the prefix trie when
+    # the routing logic has one
+    state_path = os.path.join(tempfile.mkdtemp(prefix="vpsa-router-"), "state.sock")
+    trie_srv = SharedTrieServer(state_path, args.prefix_trie_max_nodes)
+    trie_srv.start()
+    trie_path = state_path if args.routing_logic == "prefixaware" else None
     procs: dict[int, multiprocessing.Process] = {}
     stopping = threading.Event()
 
     def spawn(i: int) -> None:
-        p = ctx.Process(target=worker_main, args=(args, i, n, trie_path, rr), name=f"router-worker-{i}")
+        p = ctx.Process(target=worker_main, args=(args, i, n, trie_path, rr, state_path),
+                        name=f"router-worker-{i}")
         p.start()
         procs[i] = p
 
