@@ -109,6 +109,18 @@ def main():
             usage = out.get("usage", {})
             results.append({"seconds": round(dt, 4), "same_text_as_self_computed": out["choices"][0]["text"] == ref["choices"][0]["text"],
                             "cached_tokens": (usage.get("prompt_tokens_details") or {}).get("cached_tokens")})
+        # time to the first token of a NEW prompt: through the pair (prefill replica computes, pages
+        # travel, decode replica answers) against one replica doing everything itself
+        ttft_pd, ttft_single = [], []
+        for i in range(a.requests):
+            for path, sink in ((rp, ttft_pd), (pp, ttft_single)):
+                ids = [rng.randrange(16, 400) for _ in range(a.prompt_tokens)]
+                t0 = time.time()
+                http(f"http://127.0.0.1:{path}/v1/completions", {"model": a.model, "prompt": ids, "max_tokens": 1,
+                                                                 "temperature": 0}, timeout=120)
+                sink.append(round(time.time() - t0, 4))
+        ttft_pd.sort()
+        ttft_single.sort()
         ps = http(f"http://127.0.0.1:{pp}/debug/stats")
         ds = http(f"http://127.0.0.1:{dp}/debug/stats")
         push = ps.get("pd_push", {})
@@ -119,6 +131,9 @@ def main():
             "push_gb_per_s": round(gb / push["seconds"], 2) if push.get("seconds") else None,
             "decode_prefix_hit_tokens": ds.get("prefix_hits"), "decode_prefix_query_tokens": ds.get("prefix_queries"),
             "decode_prefill_rows": ds["prof"]["rows"], "prefill_rows": ps["prof"]["rows"],
+            "ttft_pair_s": ttft_pd, "ttft_single_replica_s": ttft_single,
+            "ttft_pair_over_single_median": round(ttft_pd[len(ttft_pd) // 2] / ttft_single[len(ttft_single) // 2], 3),
+            "push_tail_ms_per_request": round(1e3 * push.get("tail_seconds", 0.0) / max(push.get("pushes", 1), 1), 2),
             "requests_detail": results}), flush=True)
     finally:
         for p in procs:

@@ -125,34 +125,52 @@ API void* comm_rccl_init(const void* id_bytes, int nranks, int rank, int device)
 
 API int comm_rccl_destroy(void* c) { return (int)ncclCommDestroy((ncclComm_t)c); }
 
+// A transfer can be hundreds of pages; one ncclGroupStart/End around all of them would enqueue
+// that many point-to-point operations as ONE fused launch, whose size the library bounds.  The
+// pages go in groups of at most COMM_RCCL_GROUP operations: sender and receiver cut the same list
+// at the same places, so every group's sends meet their receives in order.
+#define COMM_RCCL_GROUP 64
+
+API int comm_rccl_group_limit() { return COMM_RCCL_GROUP; }
+
 API int comm_rccl_send_pages(void* c, const void* base, size_t page_bytes, const int64_t* pages, int n,
                              int peer, void* stream) {
   bind_thread();
-  ncclGroupStart();
-  for (int i = 0; i < n; ++i) {
-    ncclResult_t r = ncclSend((const char*)base + (size_t)pages[i] * page_bytes, page_bytes, ncclChar,
-                              peer, (ncclComm_t)c, (hipStream_t)stream);
-    if (r != ncclSuccess) {
-      ncclGroupEnd();
-      return (int)r;
+  for (int g0 = 0; g0 < n; g0 += COMM_RCCL_GROUP) {
+    const int g1 = g0 + COMM_RCCL_GROUP < n ? g0 + COMM_RCCL_GROUP : n;
+    ncclGroupStart();
+    for (int i = g0; i < g1; ++i) {
+      ncclResult_t r = ncclSend((const char*)base + (size_t)pages[i] * page_bytes, page_bytes, ncclChar,
+                                peer, (ncclComm_t)c, (hipStream_t)stream);
+      if (r != ncclSuccess) {
+        ncclGroupEnd();
+        return (int)r;
+      }
     }
+    ncclResult_t r = ncclGroupEnd();
+    if (r != ncclSuccess) return (int)r;
   }
-  return (int)ncclGroupEnd();
+  return 0;
 }
 
 API int comm_rccl_recv_pages(void* c, void* base, size_t page_bytes, const int64_t* pages, int n,
                              int peer, void* stream) {
   bind_thread();
-  ncclGroupStart();
-  for (int i = 0; i < n; ++i) {
-    ncclResult_t r = ncclRecv((char*)base + (size_t)pages[i] * page_bytes, page_bytes, ncclChar, peer,
-                              (ncclComm_t)c, (hipStream_t)stream);
-    if (r != ncclSuccess) {
-      ncclGroupEnd();
-      return (int)r;
+  for (int g0 = 0; g0 < n; g0 += COMM_RCCL_GROUP) {
+    const int g1 = g0 + COMM_RCCL_GROUP < n ? g0 + COMM_RCCL_GROUP : n;
+    ncclGroupStart();
+    for (int i = g0; i < g1; ++i) {
+      ncclResult_t r = ncclRecv((char*)base + (size_t)pages[i] * page_bytes, page_bytes, ncclChar, peer,
+                                (ncclComm_t)c, (hipStream_t)stream);
+      if (r != ncclSuccess) {
+        ncclGroupEnd();
+        return (int)r;
+      }
     }
+    ncclResult_t r = ncclGroupEnd();
+    if (r != ncclSuccess) return (int)r;
   }
-  return (int)ncclGroupEnd();
+  return 0;
 }
 
 // ---------------------------------------------------------------- one-shot all-reduce

@@ -342,3 +342,149 @@ def test_step_loop_does_not_wait_for_a_slow_decode_replica(monkeypatch):
         pre.shutdown()
 
     asyncio.run(go())
+
+
+def test_pool_exported_pages_land_where_they_live(stub):
+    """A decode replica whose pool is one exportable allocation hands out the pool's own handle:
+    the producer writes every page into its final place in ONE round (no window slots, no
+    commit-time copy on the decode replica) and the mode is reported as ipc-direct."""
+    async def go():
+        dec, dae, drunner, url = await _pd_pair()
+        dec.runner.pool_ipc_handle = dec.runner.pool.data_ptr().to_bytes(8, "little").hex()  # what the stub maps
+        pre = _engine("kv_producer")
+        a = _prompt(seed=21)
+        res, _ = await asyncio.get_running_loop().run_in_executor(None, _prefill_and_push, pre, a, url)
+        assert res["mode"] == "ipc-direct" and res["pages"] == 5
+        # one copy call per push job on the producer, none on the decode replica
+        assert sum(int(x.split(":")[1]) for x in stub.log if x.startswith("push_pages")) == 5
+        assert dec.bm.peek_prefix(chain_hashes(a)) == 5
+        same, cached = await _decode_matches(dae, a)
+        assert same and cached == 320
+        await drunner.cleanup()
+        dae.stop()
+        pre.shutdown()
+
+    asyncio.run(go())
+
+
+def test_pages_leave_chunk_by_chunk_while_the_prompt_is_still_being_prefilled():
+    """Chunked prefill of a 330-token prompt in chunks of 128 tokens: the pages a chunk completes
+    are handed to the push worker right after that chunk (pages are immutable once full), so the
+    transfer has several jobs and only the last chunk's pages are pushed after the last step;
+    the future the HTTP handler awaits completes after the LAST job, with the total."""
+    async def go():
+        dec, dae, drunner, url = await _pd_pair()
+        pre = LLMEngine(EngineConfig(model="tiny-llama", device="cpu", dtype="float32", max_model_len=1024,
+                                     num_gpu_blocks_override=32, host="127.0.0.1", port=0, max_num_batched_tokens=128,
+                                     kv_transfer=KVTransferConfig("LMCacheConnectorV1", "kv_producer")))
+        a = _prompt(seed=22)
+
+        def run():
+            sp = SamplingParams(max_tokens=1, temperature=0, ignore_eos=True)
+            req = pre.add_request(a, sp, kv_transfer_params={"do_remote_decode": True, "decode_target": url})
+            seen = []
+            while pre.has_work():
+                pre.step()
+                seen.append(getattr(req, "_pushed_pages", 0))
+            return req, seen, pre.connector.push_future(req.request_id).result(30)
+
+        req, seen, res = await asyncio.get_running_loop().run_in_executor(None, run)
+        assert seen == [2, 4, 5], seen  # after each of the three chunks: 128, 256, 330 tokens computed
+        assert res["mode"] == "tcp" and res["pages"] == 5 and res["jobs"] == 4  # three chunks + the closing job
+        assert dec.bm.peek_prefix(chain_hashes(a)) == 5
+        same, cached = await _decode_matches(dae, a)
+        assert same and cached == 320
+        pre.idle_tick()
+        assert pre.bm.num_free() == 32 and not any(pre.bm.ref)
+        await drunner.cleanup()
+        dae.stop()
+        pre.shutdown()
+
+    asyncio.run(go())
+
+
+def test_a_dead_target_delays_only_its_own_pushes_and_is_skipped_for_a_while(monkeypatch):
+    """Two decode targets, one of them unreachable: the transfer to the live one completes while
+    the dead one's job is still waiting for its connection to fail (one worker per target), and
+    the next push to the dead target fails at once instead of waiting again."""
+    import time
+
+    real_post = kvx._post
+
+    def post(url, payload, raw=None, timeout=10.0):
+        if "127.0.0.1:9/" in url:
+            time.sleep(1.0)
+            raise ConnectionError("connection refused")
+        return real_post(url, payload, raw, timeout)
+
+    monkeypatch.setattr(kvx, "_post", post)
+
+    async def go():
+        dec, dae, drunner, url = await _pd_pair()
+        pre = _engine("kv_producer")
+        dead = "http://127.0.0.1:9"
+
+        def run():
+            sp = SamplingParams(max_tokens=1, temperature=0, ignore_eos=True)
+            r_dead = pre.add_request(_prompt(seed=23), sp, kv_transfer_params={"do_remote_decode": True, "decode_target": dead})
+            r_live = pre.add_request(_prompt(seed=24), copy.deepcopy(sp), kv_transfer_params={"do_remote_decode": True, "decode_target": url})
+            while pre.has_work():
+                pre.step()
+            f_dead, f_live = pre.connector.push_future(r_dead.request_id), pre.connector.push_future(r_live.request_id)
+            t0 = time.time()
+            live = f_live.result(30)
+            t_live = time.time() - t0
+            dead_pending = not f_dead.done()
+            with pytest.raises(ConnectionError):
+                f_dead.result(30)
+            # within the cool-down the worker does not try again
+            r2 = pre.add_request(_prompt(seed=25), copy.deepcopy(sp), kv_transfer_params={"do_remote_decode": True, "decode_target": dead})
+            while pre.has_work():
+                pre.step()
+            t0 = time.time()
+            with pytest.raises(ConnectionError, match="skipped"):
+                pre.connector.push_future(r2.request_id).result(30)
+            return live, t_live, dead_pending, time.time() - t0
+
+        live, t_live, dead_pending, t_skip = await asyncio.get_running_loop().run_in_executor(None, run)
+        assert live["mode"] == "tcp" and t_live < 0.9 and dead_pending and t_skip < 0.5
+        pre.idle_tick()
+        assert not any(pre.bm.ref)
+        await drunner.cleanup()
+        dae.stop()
+        pre.shutdown()
+
+    asyncio.run(go())
+
+
+def test_stuck_rccl_receive_quarantines_its_pages():
+    """A receive whose sender died: the pages stay out of the allocator until the receive's event
+    fires (a late sender may still write them), the communicator is dropped, other transfers'
+    events are their own."""
+    dec = _engine("kv_consumer", pages=16)
+    recv = kvx.KVReceiver(dec)
+    page_bytes = dec.runner.pool.stride(0) * dec.runner.pool.element_size()
+
+    class Ev:
+        def __init__(self, done):
+            self.done = done
+
+        def query(self):
+            return self.done
+
+    free0 = dec.bm.num_free()
+    a = recv.reserve([101, 102], page_bytes)
+    b = recv.reserve([201], page_bytes)
+    stuck, fine = Ev(False), Ev(True)
+    recv._rccl["k1"], recv._rccl["k2"] = 1, 2
+    recv._rccl_events[tuple(a["pages"])] = (stuck, "k1")
+    recv._rccl_events[tuple(b["pages"])] = (fine, "k2")
+    assert recv.commit_begin([201], b["pages"], rccl=True) is fine  # its own event, not "the last one posted"
+    recv.commit_finish([201], b["pages"])
+    recv.commit_abort([101, 102])
+    assert dec.bm.num_free() == free0 - 2 and "k1" not in recv._rccl and "k2" in recv._rccl
+    recv.reserve([301], page_bytes)  # sweeps: still stuck
+    assert dec.bm.num_free() == free0 - 3
+    stuck.done = True
+    recv.reserve([302], page_bytes)
+    assert dec.bm.num_free() == free0 - 2  # the two quarantined pages are back, 301 and 302 are reserved

@@ -90,6 +90,7 @@ class LLMEngine:
 
         self.connector = KVConnector(self, off, kvt)
         self.scheduler.connector = self.connector
+        self.runner.pool_listeners.append(self.connector.set_pool)
         self.bm.on_evict = self.connector.on_evict
 
     # ------------------------------------------------------------------ intake
@@ -112,6 +113,9 @@ class LLMEngine:
         return req
 
     def abort(self, request_id: str) -> None:
+        live = self.requests.get(request_id)
+        if live is not None and self.connector is not None and live.kv_transfer_params:
+            self.connector.on_request_finished(live)  # closes a transfer that chunks already started
         req = self.scheduler.abort(request_id)
         self.requests.pop(request_id, None)
         if req is not None:
@@ -152,6 +156,8 @@ class LLMEngine:
             if s.start < req.prompt_len:
                 self.metrics.prompt_tokens.inc(min(s.n, req.prompt_len - s.start))
             fresh_pages.extend(self.scheduler.commit(s))
+            if self.connector is not None and req.kv_transfer_params and s.start < req.prompt_len:
+                self.connector.on_chunk_computed(req)  # P->D: this chunk's pages leave now
             if id(s) not in sampled:
                 continue
             tok, info = sampled[id(s)]

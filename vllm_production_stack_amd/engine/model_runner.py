@@ -67,9 +67,10 @@ class ModelRunner:
         self.page_bytes = self.page_elems * torch.empty((), dtype=self.dtype).element_size()
         self.max_pages_per_seq = (self.max_model_len + PAGE - 1) // PAGE
         self.num_pages = self._plan_pages()
-        self.pool = torch.zeros(
-            (self.num_pages, self.n_layers_local, 2, self.n_kv_local, PAGE * self.kv_head_dim),
-            dtype=self.dtype, device=device)
+        self.pool_listeners: list = []  # called with the new pool tensor after a wake-up
+        self._pool_dev_ptr = 0       # an allocation of our own behind the pool (exported to peers), or 0
+        self.pool_ipc_handle = None  # hex hipIpc handle of that allocation
+        self.pool = self._alloc_pool()
         self.sampler = Sampler(device, cfg.seed)
         # graphs need the HIP attention kernels (the generic path reads lengths on the host)
         self.use_graphs = (device.type == "cuda" and not cfg.enforce_eager
@@ -114,6 +115,69 @@ class ModelRunner:
         return True
 
     # ------------------------------------------------------------------ memory plan
+    def _exports_pool(self) -> bool:
+        """A decode replica of a disaggregated pair on a GPU lets its prefill peers write KV pages
+        straight into its pool (hipIpc): the pool is then one device allocation of its own, of a
+        size hipIpc can map, instead of a block of the caching allocator."""
+        import os
+
+        kt = self.cfg.kv_transfer
+        return (self.device.type == "cuda" and kt is not None and kt.kv_role in ("kv_consumer", "kv_both")
+                and os.environ.get("VPSA_PD_EXPORT_POOL", "1") != "0" and get_replica().size == 1)
+
+    def _alloc_pool(self) -> torch.Tensor:
+        shape = (self.num_pages, self.n_layers_local, 2, self.n_kv_local, PAGE * self.kv_head_dim)
+        if self._exports_pool():
+            try:
+                return self._alloc_exported_pool()
+            except Exception as e:
+                log.warning("KV pool could not be exported to prefill peers (%s): pushes land in a window", e)
+        return torch.zeros(shape, dtype=self.dtype, device=self.device)
+
+    def _alloc_exported_pool(self) -> torch.Tensor:
+        import ctypes
+
+        from ..parallel import kv_transfer as kx
+
+        pages = self.num_pages
+        while kx.ipc_safe_size(pages * self.page_bytes) != pages * self.page_bytes:
+            pages = kx.ipc_safe_size(pages * self.page_bytes) // self.page_bytes  # gives up < 2 GiB + one page
+        if pages < self.max_pages_per_seq:
+            raise MemoryError("no exportable pool size holds one sequence")
+        lib = kx.comm()
+        nbytes = pages * self.page_bytes
+        ptr = lib.comm_dev_alloc(ctypes.c_size_t(nbytes))
+        if not ptr:
+            raise MemoryError(f"hipMalloc of {nbytes >> 20} MiB failed")
+        buf = ctypes.create_string_buffer(lib.comm_ipc_handle_size())
+        if lib.comm_ipc_export(ctypes.c_void_p(ptr), buf) != 0:
+            lib.comm_dev_free(ctypes.c_void_p(ptr))
+            raise RuntimeError("hipIpcGetMemHandle failed")
+
+        class _DevMem:  # what torch.as_tensor needs to alias device memory it did not allocate
+            __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False),
+                                        "version": 2, "strides": None}
+
+        raw = torch.as_tensor(_DevMem(), device=self.device)
+        assert raw.data_ptr() == ptr
+        raw.zero_()
+        if pages != self.num_pages:
+            log.info("KV pool: %d pages instead of %d so that peers can map it", pages, self.num_pages)
+        self.num_pages = pages
+        self._pool_dev_ptr, self.pool_ipc_handle = int(ptr), buf.raw.hex()
+        return raw.view(self.dtype).view(pages, self.n_layers_local, 2, self.n_kv_local, PAGE * self.kv_head_dim)
+
+    def _free_exported_pool(self) -> None:
+        """After every tensor view of the pool is gone."""
+        if self._pool_dev_ptr:
+            import ctypes
+
+            from ..parallel import kv_transfer as kx
+
+            torch.cuda.synchronize(self.device)
+            kx.comm().comm_dev_free(ctypes.c_void_p(self._pool_dev_ptr))
+            self._pool_dev_ptr, self.pool_ipc_handle = 0, None
+
     def _plan_pages(self) -> int:
         if self.cfg.num_gpu_blocks_override:
             return int(self.cfg.num_gpu_blocks_override)
@@ -367,6 +431,7 @@ class ModelRunner:
         self.model = None
         self.sampler = None
         gc.collect()
+        self._free_exported_pool()
         if self.device.type == "cuda":
             torch.cuda.empty_cache()
 
@@ -577,6 +642,9 @@ class ModelRunner:
         freed += self.pool.numel() * self.pool.element_size()
         self._pool_shape = tuple(self.pool.shape)
         self.pool = torch.empty(0, dtype=self.dtype, device=self.device)
+        for fn in self.pool_listeners:  # nobody may keep a view of memory that is about to go
+            fn(self.pool)
+        self._free_exported_pool()  # peers re-map the new allocation (new handle) after the wake-up
         if self.device.type == "cuda":
             torch.cuda.empty_cache()
         self.sleeping = True
@@ -601,7 +669,9 @@ class ModelRunner:
                 self.model.init_random(self.cfg.seed)
             self._pack_decode_weights()
         self._sleep_stash = []
-        self.pool = torch.zeros(self._pool_shape, dtype=self.dtype, device=self.device)
+        self.pool = self._alloc_pool()
+        for fn in self.pool_listeners:  # whoever keeps the pool tensor (KV tiers) takes the new one
+            fn(self.pool)
         self.sleeping = False
         if self.cfg.capture_graphs_at_start:
             self.capture_all_graphs()

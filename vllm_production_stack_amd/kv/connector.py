@@ -96,6 +96,7 @@ class KVConnector:
         self._pending: list[tuple[object, list[int]]] = []  # (event, page ids holding a ref)
         self._pusher = None  # P->D push worker, created with the first transfer
         self._push_futures: dict = {}  # request id -> future of its transfer
+        self._push_born: dict = {}  # request id -> when that future was created (unclaimed ones are swept)
         self._bg: queue.Queue = queue.Queue()
         self._bg_thread = threading.Thread(target=self._bg_loop, name="kv-bg", daemon=True)
         self._bg_thread.start()
@@ -208,6 +209,12 @@ class KVConnector:
                              "uploads_in_flight": len(self._inflight), "pages_dropped": self.remote_dropped,
                              "serde": "cachegen" if self.serde.kind else "naive"}
         return out
+
+    def set_pool(self, pool) -> None:
+        """The runner replaced its pool tensor (sleep: an empty one; wake-up: a new allocation)."""
+        self.pool = pool
+        if self.host is not None:
+            self.host.pool = pool
 
     STAGE_WAIT_S = 2.0  # how long a download waits for a staging slot before it goes page by page
 
@@ -474,6 +481,13 @@ class KVConnector:
         """Release page references whose offload copies or P->D pushes have completed."""
         if self._pusher is not None:
             self._pusher.drain_released()
+            if len(self._push_born) > 64:
+                # a handler that was cancelled (client gone) never claims its future: forget finished
+                # ones after a while instead of keeping them for the life of the process
+                now = time.time()
+                for rid in [r for r, t in self._push_born.items() if now - t > 120 and self._push_futures[r].done()]:
+                    self._push_born.pop(rid, None)
+                    self._push_futures.pop(rid, None)
         still = []
         for ev, pages in self._pending:
             if ev.query():
@@ -496,52 +510,83 @@ class KVConnector:
             self._pd_stats = {"pushes": 0, "pages": 0, "seconds": 0.0, "by_mode": {}}
         return self._pd_stats
 
-    def on_request_finished(self, req) -> None:
-        """Engine thread, while the request still owns its pages.  A prefill request of a
-        disaggregated pair hands its pages to the push worker here: a reference per page, one
-        stream event, one queue put.  The transfer itself (control-plane round trips, the copy,
-        back-pressure of a busy decode replica) runs on that worker; the HTTP handler of the
-        request awaits ``push_future`` before it answers, so the router sends the decode request
-        only once the pages are published there."""
+    def _push_target(self, req):
+        """Where this request's pages go (a prefill request of a disaggregated pair), or None."""
         kvp = req.kv_transfer_params or {}
         if not kvp.get("do_remote_decode") or self.role == "kv_consumer":
-            return
+            return None
         target = kvp.get("decode_target")
         if not target:
-            return
-        from ..parallel.kv_transfer import PagePusher, target_allowed
+            return None
+        from ..parallel.kv_transfer import target_allowed
 
         if not target_allowed(target):
-            log.error("KV push target %r refused (not http(s) or not in VPSA_PD_ALLOWED_TARGETS)", target)
-            return
+            if not getattr(req, "_push_refused", False):
+                req._push_refused = True
+                log.error("KV push target %r refused (not http(s) or not in VPSA_PD_ALLOWED_TARGETS)", target)
+            return None
+        return target
+
+    def _submit_push(self, req, target: str, final: bool) -> None:
+        from ..parallel.kv_transfer import PagePusher
+
         n_full = min(req.num_computed // PAGE, len(req.hashes), len(req.pages))
-        if n_full == 0:
-            return
+        done = getattr(req, "_pushed_pages", 0)
+        if n_full <= done and not (final and done > 0):
+            return  # nothing new; a request that never submitted anything needs no closing job
         if self._pusher is None:
             self._pusher = PagePusher(self.engine)
-        fut = self._pusher.submit(req.request_id, target, req.hashes[:n_full], req.pages[:n_full])
-        self._push_futures[req.request_id] = fut
-        rid = req.request_id
+        first = req.request_id not in self._push_futures and done == 0
+        fut = self._pusher.submit(req.request_id, target, req.hashes[done:n_full], req.pages[done:n_full], final)
+        req._pushed_pages = n_full
+        if first:
+            import time
 
-        def done(f, rid=rid, target=target, n=n_full):
-            st = self.pd_stats
-            if f.exception() is not None:
-                st["failed"] = st.get("failed", 0) + 1
-                log.error("KV push of %s to %s failed: %s", rid, target, f.exception())
-                return
-            r = f.result()
-            st["pushes"] += 1
-            st["pages"] += n
-            st["seconds"] += r["seconds"]
-            st["by_mode"][r["mode"]] = st["by_mode"].get(r["mode"], 0) + 1
-            log.info("pushed %d KV pages of %s to %s via %s in %.1f ms", n, rid, target, r["mode"],
-                     r["seconds"] * 1e3)
+            self._push_futures[req.request_id] = fut
+            self._push_born[req.request_id] = time.time()
+            rid = req.request_id
 
-        fut.add_done_callback(done)
+            def finished(f, rid=rid, target=target):
+                st = self.pd_stats
+                if f.exception() is not None:
+                    st["failed"] = st.get("failed", 0) + 1
+                    log.error("KV push of %s to %s failed: %s", rid, target, f.exception())
+                    return
+                r = f.result()
+                st["pushes"] += 1
+                st["pages"] += r["pages"]
+                st["jobs"] = st.get("jobs", 0) + r["jobs"]
+                st["seconds"] += r["seconds"]
+                st["tail_seconds"] = st.get("tail_seconds", 0.0) + r["tail_seconds"]
+                st["by_mode"][r["mode"]] = st["by_mode"].get(r["mode"], 0) + 1
+                log.info("pushed %d KV pages of %s to %s via %s (%d jobs over %.1f ms; %.1f ms after the request's end)",
+                         r["pages"], rid, target, r["mode"], r["jobs"], r["seconds"] * 1e3, r["tail_seconds"] * 1e3)
+
+            fut.add_done_callback(finished)
+
+    def on_chunk_computed(self, req) -> None:
+        """Engine thread, after a prefill chunk of ``req`` ran: the pages it filled (and, the first
+        time, the pages it found cached) leave for the decode replica now, while the following
+        chunks are computed.  A reference per page, one stream event, one queue put."""
+        target = self._push_target(req)
+        if target is not None:
+            self._submit_push(req, target, final=False)
+
+    def on_request_finished(self, req) -> None:
+        """Engine thread, while the request still owns its pages (also for aborted requests).  A
+        prefill request of a disaggregated pair hands the pages of its last chunk to the push
+        worker here and closes its transfer.  The transfers themselves (control-plane round
+        trips, the copies, back-pressure of a busy decode replica) run on that worker; the HTTP
+        handler of the request awaits ``push_future`` before it answers, so the router sends the
+        decode request only once the pages are published there."""
+        target = self._push_target(req)
+        if target is not None:
+            self._submit_push(req, target, final=True)
 
     def push_future(self, request_id: str):
         """The transfer started for ``request_id`` when it finished (None: there was none).  Taken
         once: the caller owns it."""
+        self._push_born.pop(request_id, None)
         return self._push_futures.pop(request_id, None)
 
     def close(self) -> None:

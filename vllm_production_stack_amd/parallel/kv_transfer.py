@@ -4,14 +4,19 @@ Protocol (control plane = the replicas' own HTTP ports, data plane chosen per pa
   1. producer  POST <decode>/kv/reserve {hashes}      -> {pages, missing, transports...}
      the decode replica allocates HBM pages for the hashes it does not hold yet;
   2. producer  moves the page bytes:
-        ipc   the decode replica's LANDING WINDOW (a device allocation of its own, of a size
-              hipIpc can map: LMCACHE_NIXL_BUFFER_SIZE, default 1 GiB, see ipc_safe_size) is mapped through a hipIpc handle and written with
-              hipMemcpyAsync on a side stream (SDMA over the direct xGMI link); at commit the
-              decode replica copies window slots into its pool pages on the device.  The pool
-              itself is not exported: hipIpcOpenMemHandle never returns for allocations
-              whose size modulo 4 GiB is 2 GiB or more (benchmarks/ipc_probe.py), and a pool's
-              size follows from the memory budget.  A request with more pages than free slots goes in
-              rounds (reserve -> push -> commit, repeated),
+        ipc-direct  the decode replica's KV POOL itself is mapped through a hipIpc handle and the
+              pages are written where they will live, with hipMemcpyAsync on a side stream (SDMA
+              over the direct xGMI link); commit only publishes.  The decode replica of a pair
+              allocates its pool as one device allocation of its own, of a size hipIpc can map
+              (hipIpcOpenMemHandle never returns for allocations whose size modulo 4 GiB is 2 GiB
+              or more: benchmarks/ipc_probe.py, ``ipc_safe_size``; the page count is rounded down
+              accordingly: ``ModelRunner._alloc_exported_pool``).  The producers of a deployment
+              are trusted with the whole pool, as NIXL peers are with registered memory,
+        ipc   fallback when the pool could not be exported: a LANDING WINDOW (a device allocation
+              of LMCACHE_NIXL_BUFFER_SIZE bytes, default 1 GiB) is mapped and written the same way,
+              and at commit the decode replica copies window slots into its pool pages on the
+              device.  A request with more pages than free slots goes in rounds (reserve -> push
+              -> commit, repeated),
         rccl  ncclSend / ncclRecv of whole pages on side streams, over a two-rank RCCL
               communicator created per (prefill, decode) pair (the unique id travels over the
               control plane).  Taken automatically when both replicas have a GPU and the decode
@@ -21,11 +26,15 @@ Protocol (control plane = the replicas' own HTTP ports, data plane chosen per pa
   3. producer  POST <decode>/kv/commit {hashes, pages} -> pages are published in the decode
      replica's prefix cache; the decode request then finds its prompt resident.
 
-Neither side's step loop waits for a transfer.  On the prefill replica the engine thread only
-takes a reference on the finished request's pages, records a stream event and hands the job to a
-worker thread (``PagePusher``) with a stream of its own; the HTTP handler of the prefill request
-awaits the job's future before it answers the router, so the decode request is sent only when the
-pages are published.  On the decode replica ``commit`` enqueues the window -> pool copy on a side
+Neither side's step loop waits for a transfer, and a transfer does not wait for the end of the
+prompt: the prefill replica hands the pages of every finished prefill CHUNK to the push worker of
+their target (pages are immutable once full), so a long prompt's KV leaves while its later chunks
+are still being computed and only the last chunk's pages are on the time-to-first-token path.  The
+engine thread only takes a reference per page, records a stream event and queues the job
+(``PagePusher``: one worker thread and copy stream per decode target, so a dead target delays
+nobody else's transfer; a target that failed is skipped for a few seconds); the HTTP handler of
+the prefill request awaits the future of the request's LAST job before it answers the router, so
+the decode request is sent only when the pages are published.  On the decode replica ``commit`` enqueues the window -> pool copy on a side
 stream, a worker thread waits for its event (bounded), and only then are the pages registered in
 the prefix cache: whoever finds them there finds complete data, and nothing ever calls a
 device-wide synchronise.
@@ -279,7 +288,7 @@ def push_request_pages(engine, target: str, hashes: list[int], pages: list[int],
             try:
                 _push_ipc(pool, target, res["ipc_handle"], res.get("ipc_offset", 0), page_bytes, src,
                           res["ipc_slots"], stream)
-                mode = "ipc"
+                mode = "ipc-direct" if res.get("direct") else "ipc"
             except Exception as e:
                 log.warning("ipc push failed (%s); falling back", e)
         # RCCL when forced, or when both sides have a GPU and no landing window came back (another
@@ -311,36 +320,61 @@ def push_request_pages(engine, target: str, hashes: list[int], pages: list[int],
 
 
 class PagePusher:
-    """Worker thread of a prefill replica that moves finished requests' pages to their decode
-    replicas.  ``submit`` is called on the engine thread and returns at once with a future; the
-    pages stay referenced until the job is over, and ``drain_released`` (engine thread again)
-    gives the references back."""
+    """Moves a prefill replica's pages to their decode replicas.  ``submit`` is called on the
+    engine thread, as often per request as it has new full pages (every finished prefill chunk,
+    then once more with ``final`` when the request is over), and returns at once with the
+    request's future, which completes when the request's LAST job is over.  One worker thread
+    with a copy stream of its own per decode target: a target that does not answer costs the
+    pushes to that target their deadline and nobody else anything, and is skipped for
+    ``COOLDOWN_S`` after a failure (the decode replica recomputes what did not arrive).  Pages
+    stay referenced until their job is over; ``drain_released`` (engine thread again) gives the
+    references back."""
+
+    COOLDOWN_S = 5.0
 
     def __init__(self, engine):
         import queue
         import threading
 
         self.engine = engine
-        self._jobs: "queue.Queue" = queue.Queue()
         self._released: "queue.Queue" = queue.Queue()
-        self._stream = None
-        self._thread = threading.Thread(target=self._loop, name="kv-push", daemon=True)
-        self._thread.start()
+        self._lock = threading.Lock()
+        self._targets: dict[str, "queue.Queue"] = {}
+        self._down_until: dict[str, float] = {}
+        self._req: dict[str, dict] = {}  # request id -> progress of its transfer
 
-    def submit(self, request_id: str, target: str, hashes: list[int], pages: list[int]):
+    def submit(self, request_id: str, target: str, hashes: list[int], pages: list[int], final: bool = True):
+        import queue
+        import threading
+        import time
         from concurrent.futures import Future
 
         pool = self.engine.runner.pool
         bm = self.engine.bm
-        for p in pages:  # the request is about to give its pages back: keep them until the push is over
+        for p in pages:  # the request may give its pages back before the copy has read them
             bm.ref[p] += 1
         ready = None
-        if pool.is_cuda:
+        if pool.is_cuda and pages:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(pool.device))
-        fut: Future = Future()
-        self._jobs.put((request_id, target, list(hashes), list(pages), ready, fut))
-        return fut
+        with self._lock:
+            st = self._req.get(request_id)
+            if st is None:
+                st = self._req[request_id] = {"fut": Future(), "t0": time.time(), "pages": 0, "error": None,
+                                              "mode": "resident", "jobs": 0}
+            st["jobs"] += 1
+            if final:
+                st["t_final"] = time.time()
+            q = self._targets.get(target)
+            if q is None:
+                q = self._targets[target] = queue.Queue()
+                threading.Thread(target=self._loop, args=(target, q), name="kv-push", daemon=True).start()
+        q.put((request_id, list(hashes), list(pages), ready, final))
+        return st["fut"]
+
+    def pending(self, request_id: str) -> bool:
+        with self._lock:
+            return request_id in self._req
 
     def drain_released(self) -> None:
         """Engine thread: give back the page references of finished pushes."""
@@ -353,32 +387,54 @@ class PagePusher:
                 return
             self.engine.bm.free(pages)
 
-    def _loop(self) -> None:
+    def _loop(self, target: str, jobs) -> None:
         import time
 
         pool = self.engine.runner.pool
+        stream = None
         if pool.is_cuda:
             from .. import ops
 
             ops.ensure_device()
             torch.cuda.set_device(pool.device)
-            self._stream = torch.cuda.Stream(device=pool.device)
+            stream = torch.cuda.Stream(device=pool.device)
         while True:
-            job = self._jobs.get()
+            job = jobs.get()
             if job is None:
                 return
-            request_id, target, hashes, pages, ready, fut = job
-            t0 = time.time()
+            request_id, hashes, pages, ready, final = job
+            with self._lock:
+                st = self._req.get(request_id)
             try:
-                mode = push_request_pages(self.engine, target, hashes, pages, ready, self._stream)
-                fut.set_result({"mode": mode, "pages": len(pages), "seconds": time.time() - t0})
+                if hashes and st is not None and st["error"] is None:
+                    if time.time() < self._down_until.get(target, 0.0):
+                        raise ConnectionError(f"decode replica {target} failed a moment ago: transfer skipped")
+                    mode = push_request_pages(self.engine, target, hashes, pages, ready, stream)
+                    st["pages"] += len(pages)
+                    if mode != "resident":
+                        st["mode"] = mode
             except BaseException as e:  # the future must always complete
-                fut.set_exception(e)
+                self._down_until[target] = time.time() + self.COOLDOWN_S
+                if st is not None:
+                    st["error"] = e
             finally:
                 self._released.put(pages)
+            if final and st is not None:
+                with self._lock:
+                    self._req.pop(request_id, None)
+                if st["error"] is not None:
+                    st["fut"].set_exception(st["error"])
+                else:
+                    now = time.time()
+                    # tail_seconds: from the request's end to the publication of its last pages,
+                    # the part of the transfer that the time to first token pays for
+                    st["fut"].set_result({"mode": st["mode"], "pages": st["pages"], "jobs": st["jobs"],
+                                          "seconds": now - st["t0"], "tail_seconds": now - st.get("t_final", st["t0"])})
 
     def close(self) -> None:
-        self._jobs.put(None)
+        with self._lock:
+            for q in self._targets.values():
+                q.put(None)
 
 
 def _my_rank() -> int:
@@ -475,8 +531,11 @@ class KVReceiver:
         # a producer that died between reserve and commit must not keep pages and window slots
         self.reserve_ttl = float(os.environ.get("VPSA_PD_RESERVE_TTL_S", "120"))
         self._rccl: dict[str, int] = {}  # unique id (hex) -> communicator with one prefill replica
-        self._rccl_stream = None
-        self._rccl_event = None  # completion of the receives posted last
+        self._rccl_streams: dict[str, object] = {}  # communicator key -> its receive stream
+        self._rccl_events: dict[tuple, tuple] = {}  # pages of a posted receive -> (event, communicator key)
+        # pages of receives that never completed: a late sender may still write them, so they stay
+        # out of the allocator until their event fires (or for good, with a dead sender)
+        self._quarantine: list[tuple[object, list[int]]] = []
         self._copy_stream = None  # window -> pool copies
 
     def _landing_window(self, page_bytes: int) -> bool:
@@ -545,13 +604,30 @@ class KVReceiver:
             raise ValueError("hashes: a list of integers")
         if self._reserved_at:
             self._expire()
+        if self._quarantine:
+            self._sweep_quarantine()
         missing = [h for h in hashes if not bm.contains(h) and h not in self.reserved]
         peer = peer or {}
         slots = None
         more = False
         on_dev = _on_device(pool)
-        by_ipc = bool(missing and on_dev and peer.get("gpu") and peer.get("host_id") == host_identity() and
-                      peer.get("transport", "auto") in ("auto", "ipc") and self._landing_window(page_bytes))
+        same_host_gpu = bool(missing and on_dev and peer.get("gpu") and peer.get("host_id") == host_identity()
+                             and peer.get("transport", "auto") in ("auto", "ipc"))
+        pool_handle = getattr(self.engine.runner, "pool_ipc_handle", None)
+        if same_host_gpu and pool_handle:
+            # the pool itself is mapped by the producer: every page lands where it will live
+            if not bm.can_allocate(len(missing)):
+                raise MemoryError("decode replica has no free KV pages for the transfer")
+            pages = bm.allocate(len(missing))
+            import time
+
+            now = time.time()
+            for h, p in zip(missing, pages):
+                self.reserved[h] = p
+                self._reserved_at[h] = now
+            return {"pages": pages, "missing": missing, "more": False, "ipc_handle": pool_handle,
+                    "ipc_offset": 0, "ipc_slots": pages, "direct": True, "host_id": host_identity(), "gpu": True}
+        by_ipc = bool(same_host_gpu and self._landing_window(page_bytes))
         if by_ipc and not self._free_slots:
             # other producers fill the window right now: their commits free it within milliseconds
             return {"pages": [], "missing": [], "more": True, "busy": True, "host_id": host_identity(),
@@ -598,15 +674,18 @@ class KVReceiver:
             raise ValueError("page size mismatch")
         self._require_reserved(pages)
         c = self._rccl[key]
-        if self._rccl_stream is None and pool.is_cuda:
-            self._rccl_stream = _new_stream(pool)
+        # a stream per communicator: a receive that never completes (dead sender) blocks only the
+        # transfers of that one prefill replica
+        stream = self._rccl_streams.get(key)
+        if stream is None and pool.is_cuda:
+            stream = self._rccl_streams[key] = _new_stream(pool)
         n = len(pages)
         dp = (ctypes.c_int64 * n)(*pages)
         rc = comm().comm_rccl_recv_pages(c_void_p(c), c_void_p(pool.data_ptr()), page_bytes, dp, n, 0,
-                                         _stream_ptr(self._rccl_stream))
+                                         _stream_ptr(stream))
         if rc != 0:
             raise RuntimeError(f"ncclRecv failed ({rc})")
-        self._rccl_event = _record(self._rccl_stream)
+        self._rccl_events[tuple(pages)] = (_record(stream), key)
         return {"ok": True}
 
     def push(self, pages: list[int], raw: bytes) -> dict:
@@ -647,7 +726,10 @@ class KVReceiver:
                 raise RuntimeError(f"landing window copy failed ({rc})")
             return _record(self._copy_stream)
         if rccl:
-            return self._rccl_event
+            ent = self._rccl_events.get(tuple(pages))
+            if ent is None:
+                raise ValueError("commit of an RCCL transfer whose receive was never posted")
+            return ent[0]
         return None
 
     def commit_finish(self, hashes: list[int], pages: list[int]) -> dict:
@@ -661,19 +743,48 @@ class KVReceiver:
             self.reserved.pop(h, None)
             self._reserved_at.pop(h, None)
             bm.register(p, h)
+        self._rccl_events.pop(tuple(pages), None)
         bm.free(pages)  # published pages wait in the prefix cache (evictable, LRU)
         return {"ok": True, "published": len(pages)}
 
+    def _sweep_quarantine(self) -> None:
+        keep = []
+        for ev, pages in self._quarantine:
+            if ev.query():
+                self.engine.bm.free(pages)
+            else:
+                keep.append((ev, pages))
+        self._quarantine = keep
+
     def commit_abort(self, hashes: list[int]) -> None:
-        """The bytes never arrived (dead sender): give pages and slots back unpublished."""
+        """The bytes never arrived (dead sender): give pages and slots back unpublished.  Pages
+        with an RCCL receive still posted on them are NOT handed back: the receive may yet
+        complete and write them.  They are quarantined until its event fires, and that
+        communicator (and its stream, stuck behind the receive) is dropped, so the prefill
+        replica's next transfer sets up a new one or takes another transport."""
+        pages = [self.reserved.get(h) for h in hashes]
+        stuck = None
+        for key_pages, (ev, ckey) in list(self._rccl_events.items()):
+            if set(key_pages) & set(p for p in pages if p is not None) and not ev.query():
+                stuck = (ev, ckey)
+                self._rccl_events.pop(key_pages, None)
+        held: list[int] = []
         for h in hashes:
             self._reserved_at.pop(h, None)
             page = self.reserved.pop(h, None)
             if page is not None:
-                self.engine.bm.free([page])
+                if stuck is not None:
+                    held.append(page)
+                else:
+                    self.engine.bm.free([page])
             slot = self._slot_of.pop(h, None)
             if slot is not None:
                 self._free_slots.append(slot)
+        if stuck is not None:
+            self._quarantine.append((stuck[0], held))
+            self._rccl.pop(stuck[1], None)  # not destroyed: ncclCommDestroy would wait for the stuck receive
+            self._rccl_streams.pop(stuck[1], None)
+            log.error("RCCL receive of %d pages never completed: pages quarantined, communicator dropped", len(held))
 
     def commit(self, hashes: list[int], pages: list[int], landed: bool = False, rccl: bool = False) -> dict:
         """All three stages on the calling thread (same-process transfers and tests; the HTTP
