@@ -99,6 +99,11 @@ def parse() -> argparse.Namespace:
                     help="offered request rate per replica (1.1 is the top of the reference's single-GPU sweep)")
     ap.add_argument("--base-port", type=int, default=_default_base_port())
     ap.add_argument("--clients", type=int, default=0, help="load-generator processes (0 = auto)")
+    ap.add_argument("--layout", default="",
+                    help="whole-node layouts instead of N equal replicas (benchmarks/layouts.py): 'pd:2x6' = 2 prefill "
+                         "+ 6 decode replicas behind the router in disaggregated_prefill mode; 'multimodel' = six "
+                         "replicas of --model + a TP2 Mixtral-8x7B replica, kvaware routing, shared KV cache server. "
+                         "VPSA_BENCH_SINGLE_DEVICE=1 (+ --num-gpu-blocks) rehearses either on one card")
     ap.add_argument("--device", default="cuda", help="cpu runs a plumbing rehearsal (tiny models)")
     # internal: load-generator mode
     ap.add_argument("--client", action="store_true")
@@ -546,6 +551,12 @@ def main() -> None:
     a = parse()
     if a.client:
         client_main(a)
+        return
+    if a.layout:
+        sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+        import layouts
+
+        layouts.main(a)
         return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # direct invocation with N > 1: relaunch under torchrun, one rank per GPU

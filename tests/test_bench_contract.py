@@ -84,3 +84,51 @@ def test_a_replica_that_cannot_start_ends_the_run_on_every_rank():
     assert time.time() - t0 < 120
     assert "engine start failed on rank(s) [1]" in p.stderr, p.stderr[-2000:]
     assert not p.stdout.strip()  # no half-measured JSON line
+
+
+def _layout_line(args, timeout=600):
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--device", "cpu", "--model", "tiny-llama",
+                        "--steps", "2", "--warmup", "1", "--users-per-gpu", "2", "--warmup-users-per-gpu", "1",
+                        "--sys-len", "64", "--history-len", "300", "--answer-len", "8", "--max-model-len", "2048",
+                        "--num-gpu-blocks", "64"] + args, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_pd_layout_runs_end_to_end_on_the_cpu():
+    """``bench.py --layout pd:1x2``: one prefill and two decode replicas as processes of their own,
+    the router in disaggregated_prefill mode, the multi-round workload; every request goes prefill
+    pool -> decode pool, the pages travel (TCP between CPU replicas) chunk by chunk, and the decode
+    pool finds every pushed prefix resident."""
+    r = _layout_line(["--layout", "pd:1x2", "--base-port", "18300"])
+    assert r["failed_requests"] == 0 and r["requests"] == 8 and r["value"] > 0
+    assert r["config"]["parallelism"].startswith("pd:1x2")
+    assert r["requests_routed_prefill_then_decode"] >= 8
+    pre = r["prefill_pool"][0]
+    assert pre["pushed_pages"] > 0 and pre["failed_pushes"] == 0 and pre["push_jobs"] >= 2 * 8
+    assert sum(d["prefix_hit_tokens"] for d in r["decode_pool"]) > 0
+    assert set(r["kv_pushed_gb_by_transport"]) == {"tcp"}
+
+
+def test_multimodel_layout_runs_end_to_end_on_the_cpu():
+    """``bench.py --layout multimodel``: six dense replicas + a two-rank tensor-parallel MoE replica
+    (torch.distributed.run, gloo), the cache server and the router with kvaware routing hosting the
+    KV controller; both models answer through one router and every conversation stays on the
+    replica that holds its KV."""
+    r = _layout_line(["--layout", "multimodel", "--base-port", "18400"], timeout=900)
+    assert r["tiny-llama"]["failed_requests"] == 0 and r["tiny-mixtral"]["failed_requests"] == 0
+    assert r["tiny-llama"]["requests"] == 24 and r["tiny-mixtral"]["requests"] == 4
+    assert r["conversations_kept_on_one_replica"] == r["conversations"] == 14
+    assert any(e["model"] == "tiny-mixtral" and e["rows"] > 0 for e in r["per_replica"])
+    assert r["cache_server"]["pages_known"] > 0
