@@ -1,6 +1,9 @@
 // Tiny blocking HTTP/1.1 server (thread per connection, keep-alive) and client for the native
-// control-plane binaries.  Plain TCP only: in-cluster API access goes through a
-// `kubectl proxy` sidecar or the controller's own HTTP port.
+// control-plane binaries.  Plain TCP always; TLS on both sides when the translation unit is built
+// with -DVHTTP_TLS and linked against OpenSSL (the operator: https:// API server with the
+// service-account CA bundle and bearer token, a TLS metrics endpoint whose certificate files are
+// re-read when they change).  Without the flag an https:// URL fails to connect, nothing else
+// changes (the picker and the self-tests are built without it).
 #pragma once
 #include <arpa/inet.h>
 #include <netdb.h>
@@ -9,14 +12,74 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <sys/stat.h>
+
 #include <atomic>
 #include <cstring>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 
+#ifdef VHTTP_TLS
+#include <openssl/err.h>
+#include <openssl/ssl.h>
+#include <openssl/x509v3.h>
+#endif
+
 namespace vhttp {
+
+// One connection: a socket, and the TLS session on top of it when there is one.
+struct Conn {
+  int fd = -1;
+#ifdef VHTTP_TLS
+  SSL* ssl = nullptr;
+#endif
+};
+
+inline ssize_t conn_recv(Conn& c, void* buf, size_t n) {
+#ifdef VHTTP_TLS
+  if (c.ssl) {
+    int r = SSL_read(c.ssl, buf, (int)n);
+    return r > 0 ? r : (r == 0 ? 0 : -1);
+  }
+#endif
+  return recv(c.fd, buf, n, 0);
+}
+
+inline ssize_t conn_send(Conn& c, const void* buf, size_t n) {
+#ifdef VHTTP_TLS
+  if (c.ssl) {
+    int r = SSL_write(c.ssl, buf, (int)n);
+    return r > 0 ? r : -1;
+  }
+#endif
+  return send(c.fd, buf, n, MSG_NOSIGNAL);
+}
+
+inline void conn_close(Conn& c) {
+#ifdef VHTTP_TLS
+  if (c.ssl) {
+    SSL_shutdown(c.ssl);
+    SSL_free(c.ssl);
+    c.ssl = nullptr;
+  }
+#endif
+  if (c.fd >= 0) close(c.fd);
+  c.fd = -1;
+}
+
+// What an https:// client connection trusts.  ca_file empty = the system's default trust store;
+// insecure_skip_verify only for tests against a throw-away certificate.
+struct TlsClientConfig {
+  std::string ca_file;
+  bool insecure_skip_verify = false;
+};
+inline TlsClientConfig& tls_client_config() {
+  static TlsClientConfig cfg;
+  return cfg;
+}
 
 struct Request {
   std::string method, path, query, body;
@@ -66,12 +129,12 @@ inline long long content_length(const std::string& lower_head) {
 
 // Reads one request (head + Content-Length body) from fd.  false = connection closed, a read
 // error, or a message this server refuses to buffer (oversized head or body, bad length).
-inline bool read_message(int fd, std::string& buf, std::string& head, std::string& body) {
+inline bool read_message(Conn& fd, std::string& buf, std::string& head, std::string& body) {
   size_t hdr_end;
   while ((hdr_end = buf.find("\r\n\r\n")) == std::string::npos) {
     if (buf.size() > kMaxHeaderBytes) return false;
     char tmp[8192];
-    ssize_t n = recv(fd, tmp, sizeof tmp, 0);
+    ssize_t n = conn_recv(fd, tmp, sizeof tmp);
     if (n <= 0) return false;
     buf.append(tmp, (size_t)n);
   }
@@ -83,13 +146,19 @@ inline bool read_message(int fd, std::string& buf, std::string& head, std::strin
   size_t need = hdr_end + 4 + clen;
   while (buf.size() < need) {
     char tmp[65536];
-    ssize_t n = recv(fd, tmp, sizeof tmp, 0);
+    ssize_t n = conn_recv(fd, tmp, sizeof tmp);
     if (n <= 0) return false;
     buf.append(tmp, (size_t)n);
   }
   body = buf.substr(hdr_end + 4, clen);
   buf.erase(0, need);
   return true;
+}
+
+inline bool read_message(int fd, std::string& buf, std::string& head, std::string& body) {
+  Conn c;
+  c.fd = fd;
+  return read_message(c, buf, head, body);
 }
 
 // false when the request line is not "METHOD SP target SP HTTP/x.y".
@@ -139,6 +208,24 @@ using Handler = std::function<Response(const Request&)>;
 
 class Server {
  public:
+  // TLS: serve with this certificate chain and key (PEM files).  The files are looked at again
+  // (modification time) whenever a connection arrives, and re-read when they have changed: a
+  // rotated certificate is picked up without a restart.  Call before start(); false when the
+  // files do not load (or the build has no TLS).
+  bool use_tls(const std::string& cert_file, const std::string& key_file) {
+#ifdef VHTTP_TLS
+    std::lock_guard<std::mutex> g(tls_mu_);
+    cert_file_ = cert_file;
+    key_file_ = key_file;
+    cert_mtime_ = mtime_of(cert_file_);
+    key_mtime_ = mtime_of(key_file_);
+    return reload_tls();
+#else
+    (void)cert_file;
+    (void)key_file;
+    return false;
+#endif
+  }
   // returns the bound port (0 on failure); serves on background threads
   int start(const std::string& host, int port, Handler h) {
     handler_ = std::move(h);
@@ -182,7 +269,65 @@ class Server {
       std::thread([this, c] { serve(c); }).detach();
     }
   }
-  void serve(int c) {
+#ifdef VHTTP_TLS
+  static long long mtime_of(const std::string& f) {
+    struct stat st{};
+    return stat(f.c_str(), &st) == 0 ? (long long)st.st_mtime * 1000000000LL + st.st_mtim.tv_nsec : -1;
+  }
+  bool reload_tls() {
+    SSL_CTX* ctx = SSL_CTX_new(TLS_server_method());
+    if (!ctx) return false;
+    SSL_CTX_set_min_proto_version(ctx, TLS1_2_VERSION);
+    if (SSL_CTX_use_certificate_chain_file(ctx, cert_file_.c_str()) != 1 ||
+        SSL_CTX_use_PrivateKey_file(ctx, key_file_.c_str(), SSL_FILETYPE_PEM) != 1 ||
+        SSL_CTX_check_private_key(ctx) != 1) {
+      SSL_CTX_free(ctx);
+      return false;
+    }
+    if (tls_ctx_) SSL_CTX_free(tls_ctx_);  // sessions in flight hold their own reference
+    tls_ctx_ = ctx;
+    tls_on_ = true;
+    return true;
+  }
+  SSL* accept_tls(int c) {
+    SSL* ssl;
+    {
+      std::lock_guard<std::mutex> g(tls_mu_);
+      long long cm = mtime_of(cert_file_), km = mtime_of(key_file_);
+      if (cm != cert_mtime_ || km != key_mtime_) {
+        // a half-written pair fails to load and the old certificate stays; the new times are
+        // remembered either way, so a broken file is not parsed again for every connection
+        reload_tls();
+        cert_mtime_ = cm;
+        key_mtime_ = km;
+      }
+      ssl = SSL_new(tls_ctx_);
+    }
+    if (!ssl) return nullptr;
+    timeval tv{10, 0};  // a peer that never finishes the handshake must not hold a thread for ever
+    setsockopt(c, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+    SSL_set_fd(ssl, c);
+    if (SSL_accept(ssl) != 1) {
+      SSL_free(ssl);
+      return nullptr;
+    }
+    timeval none{0, 0};
+    setsockopt(c, SOL_SOCKET, SO_RCVTIMEO, &none, sizeof none);
+    return ssl;
+  }
+#endif
+  void serve(int cfd) {
+    Conn c;
+    c.fd = cfd;
+#ifdef VHTTP_TLS
+    if (tls_on_) {
+      c.ssl = accept_tls(cfd);
+      if (!c.ssl) {
+        close(cfd);
+        return;
+      }
+    }
+#endif
     std::string buf, head, body;
     while (read_message(c, buf, head, body)) {
       Request r;
@@ -205,24 +350,34 @@ class Server {
                         "\r\nConnection: keep-alive\r\n\r\n" + resp.body;
       size_t off = 0;
       while (off < out.size()) {
-        ssize_t n = send(c, out.data() + off, out.size() - off, MSG_NOSIGNAL);
+        ssize_t n = conn_send(c, out.data() + off, out.size() - off);
         if (n <= 0) {
-          close(c);
+          conn_close(c);
           return;
         }
         off += (size_t)n;
       }
     }
-    close(c);
+    conn_close(c);
   }
   Handler handler_;
   int fd_ = -1;
   std::atomic<bool> running_{false};
   std::thread acceptor_;
+#ifdef VHTTP_TLS
+  std::string cert_file_, key_file_;
+  SSL_CTX* tls_ctx_ = nullptr;  // guarded by tls_mu_, like the two times below
+  std::atomic<bool> tls_on_{false};
+  std::mutex tls_mu_;
+  long long cert_mtime_ = -1, key_mtime_ = -1;
+#endif
 };
 
-// Splits http://host:port[/prefix] and connects; returns the socket (-1 on failure).
-inline int connect_url(const std::string& url, std::string* host_out, std::string* prefix_out, int timeout_s) {
+// Splits http[s]://host:port[/prefix] and connects (https: TLS handshake, certificate verified
+// against tls_client_config() and the host name or address); fd < 0 on failure.
+inline Conn connect_url(const std::string& url, std::string* host_out, std::string* prefix_out, int timeout_s) {
+  Conn out;
+  const bool https = url.compare(0, 8, "https://") == 0;
   std::string rest = url.substr(url.find("://") == std::string::npos ? 0 : url.find("://") + 3);
   std::string prefix;
   size_t slash = rest.find('/');
@@ -231,16 +386,17 @@ inline int connect_url(const std::string& url, std::string* host_out, std::strin
     rest = rest.substr(0, slash);
   }
   while (!prefix.empty() && prefix.back() == '/') prefix.pop_back();
-  std::string host = rest, port = "80";
+  std::string host = rest, port = https ? "443" : "80";
   size_t colon = rest.rfind(':');
-  if (colon != std::string::npos) {
+  if (colon != std::string::npos && rest.find(']', colon) == std::string::npos) {
     host = rest.substr(0, colon);
     port = rest.substr(colon + 1);
   }
+  if (host.size() > 2 && host.front() == '[' && host.back() == ']') host = host.substr(1, host.size() - 2);  // [v6]
   addrinfo hints{}, *res = nullptr;
   hints.ai_family = AF_UNSPEC;
   hints.ai_socktype = SOCK_STREAM;
-  if (getaddrinfo(host.c_str(), port.c_str(), &hints, &res) != 0 || !res) return -1;
+  if (getaddrinfo(host.c_str(), port.c_str(), &hints, &res) != 0 || !res) return out;
   int fd = socket(res->ai_family, res->ai_socktype, res->ai_protocol);
   if (fd >= 0) {
     timeval tv{timeout_s, 0};
@@ -254,13 +410,68 @@ inline int connect_url(const std::string& url, std::string* host_out, std::strin
   freeaddrinfo(res);
   if (host_out) *host_out = host;
   if (prefix_out) *prefix_out = prefix;
-  return fd;
+  if (fd < 0) return out;
+  if (https) {
+#ifdef VHTTP_TLS
+    static SSL_CTX* ctx = nullptr;
+    static std::mutex mu;
+    static std::string ctx_ca;
+    const TlsClientConfig& cfg = tls_client_config();
+    {
+      std::lock_guard<std::mutex> g(mu);
+      if (!ctx || ctx_ca != cfg.ca_file) {  // (re)built when the trust anchor is configured
+        SSL_CTX* fresh = SSL_CTX_new(TLS_client_method());
+        if (fresh) {
+          SSL_CTX_set_min_proto_version(fresh, TLS1_2_VERSION);
+          bool ok = cfg.ca_file.empty() ? SSL_CTX_set_default_verify_paths(fresh) == 1
+                                        : SSL_CTX_load_verify_locations(fresh, cfg.ca_file.c_str(), nullptr) == 1;
+          if (!ok) {
+            SSL_CTX_free(fresh);
+            fresh = nullptr;
+          }
+        }
+        if (fresh) {
+          if (ctx) SSL_CTX_free(ctx);
+          ctx = fresh;
+          ctx_ca = cfg.ca_file;
+        }
+      }
+    }
+    SSL* ssl = ctx ? SSL_new(ctx) : nullptr;
+    bool ok = ssl != nullptr;
+    if (ok) {
+      SSL_set_fd(ssl, fd);
+      if (!cfg.insecure_skip_verify) {
+        SSL_set_verify(ssl, SSL_VERIFY_PEER, nullptr);
+        in_addr a4{};
+        in6_addr a6{};
+        X509_VERIFY_PARAM* vp = SSL_get0_param(ssl);
+        if (inet_pton(AF_INET, host.c_str(), &a4) == 1 || inet_pton(AF_INET6, host.c_str(), &a6) == 1)
+          ok = X509_VERIFY_PARAM_set1_ip_asc(vp, host.c_str()) == 1;  // the API server by cluster IP
+        else
+          ok = SSL_set1_host(ssl, host.c_str()) == 1 && SSL_set_tlsext_host_name(ssl, host.c_str()) == 1;
+      }
+      ok = ok && SSL_connect(ssl) == 1;
+    }
+    if (!ok) {
+      if (ssl) SSL_free(ssl);
+      close(fd);
+      return out;
+    }
+    out.ssl = ssl;
+#else
+    close(fd);
+    return out;  // built without TLS
+#endif
+  }
+  out.fd = fd;
+  return out;
 }
 
-inline bool send_all(int fd, const std::string& data) {
+inline bool send_all(Conn& fd, const std::string& data) {
   size_t off = 0;
   while (off < data.size()) {
-    ssize_t n = send(fd, data.data() + off, data.size() - off, MSG_NOSIGNAL);
+    ssize_t n = conn_send(fd, data.data() + off, data.size() - off);
     if (n <= 0) return false;
     off += (size_t)n;
   }
@@ -294,25 +505,25 @@ inline int request(const std::string& method, const std::string& url, const std:
                    const std::string& body, std::string* out, const std::string& content_type = "application/json",
                    const std::string& bearer = "") {
   std::string host, prefix;
-  int fd = connect_url(url, &host, &prefix, 10);
-  if (fd < 0) return 0;
+  Conn fd = connect_url(url, &host, &prefix, 10);
+  if (fd.fd < 0) return 0;
   std::string req = method + " " + prefix + path + " HTTP/1.1\r\nHost: " + host + "\r\nConnection: close\r\n";
   if (!bearer.empty()) req += "Authorization: Bearer " + bearer + "\r\n";
   if (!body.empty() || method == "POST" || method == "PUT" || method == "PATCH")
     req += "Content-Type: " + content_type + "\r\nContent-Length: " + std::to_string(body.size()) + "\r\n";
   req += "\r\n" + body;
   if (!send_all(fd, req)) {
-    close(fd);
+    conn_close(fd);
     return 0;
   }
   std::string resp;
   char tmp[65536];
   ssize_t n;
-  while ((n = recv(fd, tmp, sizeof tmp, 0)) > 0) {
+  while ((n = conn_recv(fd, tmp, sizeof tmp)) > 0) {
     resp.append(tmp, (size_t)n);
     if (resp.size() > kMaxBodyBytes + kMaxHeaderBytes) break;
   }
-  close(fd);
+  conn_close(fd);
   size_t he = resp.find("\r\n\r\n");
   if (he == std::string::npos || resp.size() < 12 || resp.compare(0, 5, "HTTP/") != 0) return 0;
   int status = atoi(resp.c_str() + 9);
@@ -330,28 +541,28 @@ inline int request(const std::string& method, const std::string& url, const std:
 inline int stream_lines(const std::string& url, const std::string& path, const std::string& bearer,
                         const std::function<bool(const std::string&)>& on_line, int idle_timeout_s = 60) {
   std::string host, prefix;
-  int fd = connect_url(url, &host, &prefix, idle_timeout_s);
-  if (fd < 0) return 0;
+  Conn fd = connect_url(url, &host, &prefix, idle_timeout_s);
+  if (fd.fd < 0) return 0;
   std::string req = "GET " + prefix + path + " HTTP/1.1\r\nHost: " + host + "\r\nConnection: close\r\nAccept: application/json\r\n";
   if (!bearer.empty()) req += "Authorization: Bearer " + bearer + "\r\n";
   req += "\r\n";
   if (!send_all(fd, req)) {
-    close(fd);
+    conn_close(fd);
     return 0;
   }
   std::string buf;
   char tmp[16384];
   size_t he;
   while ((he = buf.find("\r\n\r\n")) == std::string::npos) {
-    ssize_t n = recv(fd, tmp, sizeof tmp, 0);
+    ssize_t n = conn_recv(fd, tmp, sizeof tmp);
     if (n <= 0 || buf.size() > kMaxHeaderBytes) {
-      close(fd);
+      conn_close(fd);
       return 0;
     }
     buf.append(tmp, (size_t)n);
   }
   if (buf.compare(0, 5, "HTTP/") != 0 || buf.size() < 12) {
-    close(fd);
+    conn_close(fd);
     return 0;
   }
   int status = atoi(buf.c_str() + 9);
@@ -395,11 +606,11 @@ inline int stream_lines(const std::string& url, const std::string& path, const s
       if (!line.empty() && !on_line(line)) go = false;
     }
     if (!go || eof || data.size() > kMaxBodyBytes) break;
-    ssize_t n = recv(fd, tmp, sizeof tmp, 0);
+    ssize_t n = conn_recv(fd, tmp, sizeof tmp);
     if (n <= 0) break;
     raw.append(tmp, (size_t)n);
   }
-  close(fd);
+  conn_close(fd);
   return status;
 }
 

@@ -5,11 +5,22 @@
 //       print the desired child objects as a JSON List (pipe into `kubectl apply -f -`)
 //   vpsa-operator plan-lora < {"cr": <LoraAdapter>, "pods": [{name, ip, ready, adapters[]}], "deleting": bool}
 //       print the load / unload actions the reconciler would take
-//   vpsa-operator run --api http://127.0.0.1:8001 [--namespace ns] [--interval 30] [--gpu-resource amd.com/gpu]
+//   vpsa-operator run [--api URL] [--namespace ns] [--interval 30] [--gpu-resource amd.com/gpu]
 //                     [--leader-elect --leader-elect-namespace ns --leader-id id] [--health-port 8081]
-//       control loop against the API server (reached through `kubectl proxy` or any plain-HTTP
-//       endpoint): ensure child objects, update drifted fields, write CR status, load/unload
-//       LoRA adapters on engine pods, honour finalizers.
+//                     [--ca-file f] [--token-file f] [--insecure-skip-tls-verify]
+//                     [--metrics-bind-address :8443] [--metrics-secure[=false]]
+//                     [--metrics-cert-path dir [--metrics-cert-name tls.crt] [--metrics-cert-key tls.key]]
+//       control loop against the API server: ensure child objects, update drifted fields, write
+//       CR status, load/unload LoRA adapters on engine pods, honour finalizers.
+//       Without --api, inside a pod: https://$KUBERNETES_SERVICE_HOST:$KUBERNETES_SERVICE_PORT,
+//       verified against the service account's ca.crt and authenticated with its token (the
+//       token file is read again every minute: bound tokens are rotated by the kubelet).  With
+//       --api http://... any plain endpoint (a `kubectl proxy`, a test server) still works.
+//       --metrics-bind-address serves /metrics on a port of its own: over TLS unless
+//       --metrics-secure=false (the certificate from --metrics-cert-path, picked up again when the
+//       files change; a self-signed one made at start otherwise), and, when secure, only for
+//       callers whose bearer token the API server authenticates (TokenReview) and authorizes for
+//       `get /metrics` (SubjectAccessReview).
 //       Event-driven: one watch stream per custom resource kind plus one on the engine pods
 //       (?watch=true&resourceVersion=...) wakes the reconciler as soon as something changes; the
 //       interval is only the resync period.  With --leader-elect only the holder of the Lease
@@ -21,6 +32,7 @@
 // leader election id :187, health and ready probes :252-259, four reconcilers :205-233) and the
 // pod-ready watch predicate of /root/reference/operator/internal/controller/loraadapter_controller.go:234-275;
 // the reconcile semantics are cited in reconcile.hpp.
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -29,6 +41,7 @@
 #include <csignal>
 #include <cstdio>
 #include <ctime>
+#include <fstream>
 #include <iostream>
 #include <iterator>
 #include <mutex>
@@ -78,11 +91,39 @@ struct Metrics {
 };
 static Metrics g_metrics;
 
+static std::string read_file_trimmed(const std::string& path) {
+  std::ifstream f(path);
+  std::string s((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  while (!s.empty() && (s.back() == '\n' || s.back() == '\r' || s.back() == ' ')) s.pop_back();
+  return s;
+}
+
+// The bearer token of the API client: fixed (--token) or a file that is read again once a minute
+// (a projected service-account token is replaced by the kubelet well before it expires).
+struct TokenSource {
+  std::mutex mu;
+  std::string fixed, file, cached;
+  time_t read_at = 0;
+  std::string get() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (file.empty()) return fixed;
+    time_t now = time(nullptr);
+    if (cached.empty() || now - read_at >= 60) {
+      std::string t = read_file_trimmed(file);
+      if (!t.empty()) cached = t;  // an unreadable file keeps the last good token
+      read_at = now;
+    }
+    return cached;
+  }
+};
+static TokenSource g_token;
+
 struct Api {
-  std::string base, token;
+  std::string base;
+  std::string bearer() const { return g_token.get(); }
   int get(const std::string& path, Value* out) const {
     std::string body;
-    int st = vhttp::request("GET", base, path, "", &body, "application/json", token);
+    int st = vhttp::request("GET", base, path, "", &body, "application/json", bearer());
     if (st == 200 && out) {
       try {
         *out = vjson::parse(body);
@@ -94,9 +135,124 @@ struct Api {
   }
   int send(const std::string& method, const std::string& path, const Value& obj, const std::string& ctype = "application/json") const {
     std::string body;
-    return vhttp::request(method, base, path, vjson::dump(obj), &body, ctype, token);
+    return vhttp::request(method, base, path, vjson::dump(obj), &body, ctype, bearer());
+  }
+  // POST that hands back the reply (review objects: the verdict is in the created object's status)
+  int post(const std::string& path, const Value& obj, Value* out) const {
+    std::string body;
+    int st = vhttp::request("POST", base, path, vjson::dump(obj), &body, "application/json", bearer());
+    if (st >= 200 && st < 300 && out) {
+      try {
+        *out = vjson::parse(body);
+      } catch (...) {
+        return 0;
+      }
+    }
+    return st;
   }
 };
+
+// ------------------------------------------------------------------ who may read /metrics
+// The caller's bearer token is authenticated by the API server (TokenReview) and the user it
+// names must be allowed `get` on the non-resource URL /metrics (SubjectAccessReview): the same
+// two questions the reference's metrics filter asks
+// (/root/reference/operator/cmd/main.go:146-152).  Verdicts are kept for a short while so a
+// scrape every few seconds is not two API calls each time.
+struct MetricsAuth {
+  struct Verdict {
+    int status;
+    time_t at;
+  };
+  std::mutex mu;
+  std::map<std::string, Verdict> cache;
+  static constexpr int kAllowTtl = 60, kDenyTtl = 10;
+
+  // 200 allowed, 401 not authenticated, 403 authenticated but not authorized, 500 review failed
+  int check(const Api& api, const std::string& authorization) {
+    if (authorization.compare(0, 7, "Bearer ") != 0 || authorization.size() <= 7) return 401;
+    std::string token = authorization.substr(7);
+    time_t now = time(nullptr);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = cache.find(token);
+      if (it != cache.end() && now - it->second.at < (it->second.status == 200 ? kAllowTtl : kDenyTtl)) return it->second.status;
+      if (cache.size() > 1024) cache.clear();
+    }
+    int status = review(api, token);
+    if (status != 500) {
+      std::lock_guard<std::mutex> lk(mu);
+      cache[token] = Verdict{status, now};
+    }
+    return status;
+  }
+
+  static int review(const Api& api, const std::string& token) {
+    Value tr = Value::object();
+    tr.set("apiVersion", "authentication.k8s.io/v1");
+    tr.set("kind", "TokenReview");
+    tr["spec"].set("token", token);
+    Value tr_out;
+    int st = api.post("/apis/authentication.k8s.io/v1/tokenreviews", tr, &tr_out);
+    if (st < 200 || st >= 300) return 500;
+    if (!tr_out.flag("status.authenticated")) return 401;
+    Value sar = Value::object();
+    sar.set("apiVersion", "authorization.k8s.io/v1");
+    sar.set("kind", "SubjectAccessReview");
+    Value& spec = sar["spec"];
+    spec.set("user", tr_out.s("status.user.username"));
+    const Value& groups = tr_out.at("status.user.groups");
+    if (groups.is_arr()) spec.set("groups", groups);
+    const Value& uid = tr_out.at("status.user.uid");
+    if (uid.is_str()) spec.set("uid", uid);
+    spec["nonResourceAttributes"].set("path", "/metrics");
+    spec["nonResourceAttributes"].set("verb", "get");
+    Value sar_out;
+    st = api.post("/apis/authorization.k8s.io/v1/subjectaccessreviews", sar, &sar_out);
+    if (st < 200 || st >= 300) return 500;
+    return sar_out.flag("status.allowed") ? 200 : 403;
+  }
+};
+
+#ifdef VHTTP_TLS
+// A throw-away certificate for the metrics port when none is mounted (what controller-runtime
+// does for the reference, /root/reference/operator/cmd/main.go:154-156): P-256 key, one year,
+// written 0600 into a private temp directory.
+static bool make_self_signed(std::string* cert_file, std::string* key_file) {
+  char dir[] = "/tmp/vpsa-operator-tls-XXXXXX";
+  if (!mkdtemp(dir)) return false;
+  EVP_PKEY* key = EVP_EC_gen("P-256");
+  X509* crt = X509_new();
+  bool ok = key && crt;
+  if (ok) {
+    X509_set_version(crt, 2);
+    ASN1_INTEGER_set(X509_get_serialNumber(crt), (long)time(nullptr));
+    X509_gmtime_adj(X509_getm_notBefore(crt), -300);
+    X509_gmtime_adj(X509_getm_notAfter(crt), 365L * 24 * 3600);
+    X509_set_pubkey(crt, key);
+    X509_NAME* name = X509_get_subject_name(crt);
+    X509_NAME_add_entry_by_txt(name, "CN", MBSTRING_ASC, (const unsigned char*)"vpsa-operator-metrics", -1, -1, 0);
+    X509_set_issuer_name(crt, name);
+    ok = X509_sign(crt, key, EVP_sha256()) > 0;
+  }
+  *cert_file = std::string(dir) + "/tls.crt";
+  *key_file = std::string(dir) + "/tls.key";
+  if (ok) {
+    FILE* f = fopen(cert_file->c_str(), "w");
+    ok = f && PEM_write_X509(f, crt) == 1;
+    if (f) fclose(f);
+  }
+  if (ok) {
+    mode_t old = umask(0077);
+    FILE* f = fopen(key_file->c_str(), "w");
+    umask(old);
+    ok = f && PEM_write_PrivateKey(f, key, nullptr, nullptr, 0, nullptr, nullptr) == 1;
+    if (f) fclose(f);
+  }
+  if (crt) X509_free(crt);
+  if (key) EVP_PKEY_free(key);
+  return ok;
+}
+#endif
 
 static std::string plural(const std::string& kind) {
   if (kind == "Deployment") return "deployments";
@@ -396,7 +552,7 @@ static void watch_loop(Api api, std::string list_path, std::string label) {
     if (api.get(list_path, &list) == 200) rv = list.s("metadata.resourceVersion");
     std::string path = list_path + sep + "watch=true&allowWatchBookmarks=true&timeoutSeconds=300";
     if (!rv.empty()) path += "&resourceVersion=" + rv;
-    int st = vhttp::stream_lines(api.base, path, api.token, [&](const std::string& line) {
+    int st = vhttp::stream_lines(api.base, path, api.bearer(), [&](const std::string& line) {
       if (g_stop) return false;
       try {
         Value ev = vjson::parse(line);
@@ -482,7 +638,7 @@ static std::string slurp_stdin() { return std::string(std::istreambuf_iterator<c
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    fprintf(stderr, "usage: vpsa-operator render <Kind> | plan-lora | run --api URL [--namespace ns] [--interval s] [--leader-elect] [--health-port p]\n");
+    fprintf(stderr, "usage: vpsa-operator render <Kind> | plan-lora | run [--api URL] [--namespace ns] [--interval s] [--leader-elect] [--health-port p] [--metrics-bind-address :8443 [--metrics-secure=false] [--metrics-cert-path dir]] [--ca-file f] [--token-file f]\n");
     return 2;
   }
   std::string mode = argv[1];
@@ -532,13 +688,30 @@ int main(int argc, char** argv) {
     if (mode == "run") {
       Api api;
       std::string ns, gpu = "amd.com/gpu", lease_ns, leader_id;
+      std::string ca_file, token_file, metrics_addr, metrics_cert_path, metrics_cert_name = "tls.crt", metrics_cert_key = "tls.key";
       int interval = 30, health_port = 8081, lease_s = 15;
-      bool once = false, leader_elect = false, watch = true;
+      bool once = false, leader_elect = false, watch = true, metrics_secure = true, skip_verify = false;
       for (int i = 2; i < argc; ++i) {
-        std::string a = argv[i];
-        auto next = [&]() -> std::string { return i + 1 < argc ? argv[++i] : ""; };
+        std::string a = argv[i], inline_value;
+        bool has_inline = false;  // --flag=value is the same as --flag value
+        size_t eq = a.find('=');
+        if (a.compare(0, 2, "--") == 0 && eq != std::string::npos && a.compare(0, 16, "--metrics-secure") != 0) {
+          inline_value = a.substr(eq + 1);
+          a = a.substr(0, eq);
+          has_inline = true;
+        }
+        auto next = [&]() -> std::string { return has_inline ? inline_value : i + 1 < argc ? argv[++i] : ""; };
         if (a == "--api") api.base = next();
-        else if (a == "--token") api.token = next();
+        else if (a == "--token") g_token.fixed = next();
+        else if (a == "--token-file") token_file = next();
+        else if (a == "--ca-file") ca_file = next();
+        else if (a == "--insecure-skip-tls-verify") skip_verify = true;
+        else if (a == "--metrics-bind-address") metrics_addr = next();
+        else if (a == "--metrics-secure" || a == "--metrics-secure=true") metrics_secure = true;
+        else if (a == "--metrics-secure=false") metrics_secure = false;
+        else if (a == "--metrics-cert-path") metrics_cert_path = next();
+        else if (a == "--metrics-cert-name") metrics_cert_name = next();
+        else if (a == "--metrics-cert-key") metrics_cert_key = next();
         else if (a == "--namespace") ns = next();
         else if (a == "--interval") interval = atoi(next().c_str());
         else if (a == "--gpu-resource") gpu = next();
@@ -551,10 +724,40 @@ int main(int argc, char** argv) {
         else if (a == "--no-watch") watch = false;
         else if (a == "--once") once = true;
       }
+      // inside a pod: the API server's address comes from the environment, its CA bundle and
+      // this pod's token from the service-account volume (VPSA_SA_DIR relocates it for tests)
+      const char* sa_env = getenv("VPSA_SA_DIR");
+      const std::string sa_dir = sa_env ? sa_env : "/var/run/secrets/kubernetes.io/serviceaccount";
+      const bool have_sa = access((sa_dir + "/token").c_str(), R_OK) == 0;
       if (api.base.empty()) {
-        fprintf(stderr, "--api is required (e.g. http://127.0.0.1:8001 from `kubectl proxy`)\n");
+        const char* h = getenv("KUBERNETES_SERVICE_HOST");
+        const char* p = getenv("KUBERNETES_SERVICE_PORT");
+        if (h && *h) {
+          std::string host = h;
+          if (host.find(':') != std::string::npos) host = "[" + host + "]";  // IPv6 cluster
+          api.base = "https://" + host + ":" + (p && *p ? p : "443");
+        }
+      }
+      if (api.base.empty()) {
+        fprintf(stderr, "no API server: pass --api URL, or run in a pod (KUBERNETES_SERVICE_HOST)\n");
         return 2;
       }
+      const bool https = api.base.compare(0, 8, "https://") == 0;
+      if (https) {
+#ifndef VHTTP_TLS
+        fprintf(stderr, "this build has no TLS: %s cannot be reached\n", api.base.c_str());
+        return 2;
+#endif
+        if (ca_file.empty() && access((sa_dir + "/ca.crt").c_str(), R_OK) == 0) ca_file = sa_dir + "/ca.crt";
+        vhttp::tls_client_config().ca_file = ca_file;
+        vhttp::tls_client_config().insecure_skip_verify = skip_verify;
+      }
+      if (token_file.empty() && g_token.fixed.empty() && https && have_sa) token_file = sa_dir + "/token";
+      g_token.file = token_file;
+      if (ns.empty() && getenv("VPSA_WATCH_OWN_NAMESPACE")) ns = read_file_trimmed(sa_dir + "/namespace");
+      fprintf(stderr, "[operator] API server %s (%s, %s)\n", api.base.c_str(),
+              https ? (skip_verify ? "TLS, certificate NOT verified" : ca_file.empty() ? "TLS, system trust store" : "TLS, CA bundle") : "plain HTTP",
+              !token_file.empty() ? "service-account token" : g_token.fixed.empty() ? "no token" : "fixed token");
       if (once) {
         run_once(api, ns, gpu);
         return 0;
@@ -582,7 +785,8 @@ int main(int argc, char** argv) {
             // ready = taking part in the election (leader or standby); both may be sent traffic-free probes
             resp.status = election_alive ? 200 : 503;
             resp.body = election_alive ? "ok" : "election loop not running";
-          } else if (r.path == "/metrics") {
+          } else if (r.path == "/metrics" && metrics_addr.empty()) {
+            // no metrics port of its own: the probe port carries the series (plain, unprotected)
             resp.content_type = "text/plain; version=0.0.4";
             resp.body = g_metrics.render();
           } else {
@@ -592,6 +796,57 @@ int main(int argc, char** argv) {
           return resp;
         });
         if (!bound) fprintf(stderr, "could not bind health port %d\n", health_port);
+      }
+      vhttp::Server metrics_srv;
+      MetricsAuth metrics_auth;
+      if (!metrics_addr.empty() && metrics_addr != "0") {
+        std::string mhost = "0.0.0.0";
+        size_t colon = metrics_addr.rfind(':');
+        int mport = atoi(metrics_addr.substr(colon == std::string::npos ? 0 : colon + 1).c_str());
+        if (colon != std::string::npos && colon > 0) mhost = metrics_addr.substr(0, colon);
+        if (metrics_secure) {
+#ifdef VHTTP_TLS
+          std::string crt, key;
+          if (!metrics_cert_path.empty()) {
+            crt = metrics_cert_path + "/" + metrics_cert_name;
+            key = metrics_cert_path + "/" + metrics_cert_key;
+          } else if (!make_self_signed(&crt, &key)) {
+            fprintf(stderr, "could not make a self-signed certificate for the metrics port\n");
+            return 1;
+          }
+          if (!metrics_srv.use_tls(crt, key)) {
+            fprintf(stderr, "could not load the metrics certificate %s / %s\n", crt.c_str(), key.c_str());
+            return 1;
+          }
+#else
+          fprintf(stderr, "this build has no TLS: use --metrics-secure=false\n");
+          return 2;
+#endif
+        }
+        int bound = metrics_srv.start(mhost, mport, [&, metrics_secure](const vhttp::Request& r) {
+          vhttp::Response resp;
+          resp.content_type = "text/plain";
+          if (r.path != "/metrics") {
+            resp.status = 404;
+            resp.body = "not found";
+            return resp;
+          }
+          if (metrics_secure) {
+            auto it = r.headers.find("authorization");
+            int verdict = metrics_auth.check(api, it == r.headers.end() ? "" : it->second);
+            g_metrics.add("vpsa_operator_metrics_scrapes_total{code=\"" + std::to_string(verdict) + "\"}");
+            if (verdict != 200) {
+              resp.status = verdict;
+              resp.body = verdict == 401 ? "Unauthorized" : verdict == 403 ? "Forbidden" : "could not review the token";
+              return resp;
+            }
+          }
+          resp.content_type = "text/plain; version=0.0.4";
+          resp.body = g_metrics.render();
+          return resp;
+        });
+        if (!bound) fprintf(stderr, "could not bind the metrics address %s\n", metrics_addr.c_str());
+        else fprintf(stderr, "[operator] metrics on %s:%d (%s)\n", mhost.c_str(), bound, metrics_secure ? "TLS, token review" : "plain HTTP");
       }
       std::vector<std::thread> threads;
       if (leader_elect)
@@ -632,6 +887,7 @@ int main(int argc, char** argv) {
         if (by_event) usleep(200 * 1000);  // a burst of events becomes one pass, not one pass each
       }
       health.stop();
+      metrics_srv.stop();
       for (auto& t : threads) t.detach();  // blocked in reads with a timeout; the process is exiting
       return 0;
     }

@@ -1,7 +1,10 @@
 """In-process stand-in for the Kubernetes API server, as far as the native operator uses it:
 typed object store with resourceVersions, merge-patch, the status subresource, optimistic
 concurrency on PUT (409 on a stale resourceVersion), list + watch streams (one JSON event per
-line, chunked) for custom resources and pods, and Leases.  Plays the role envtest plays for the
+line, chunked) for custom resources and pods, and Leases; optionally over TLS, with a bearer
+token required on every call, and with the TokenReview / SubjectAccessReview endpoints a secured
+metrics port asks (tokens and their users in ``users``, users allowed ``get /metrics`` in
+``metrics_readers``).  Plays the role envtest plays for the
 reference's controller tests (/root/reference/operator/internal/controller/suite_test.go:52-82)."""
 
 from __future__ import annotations
@@ -26,7 +29,11 @@ def _merge(dst: dict, patch: dict) -> dict:
 
 
 class FakeKube:
-    def __init__(self):
+    def __init__(self, tls: tuple[str, str] | None = None, token: str | None = None):
+        self.tls = tls  # (certificate chain file, key file): serve https
+        self.token = token  # every call must carry it as a bearer token
+        self.users: dict[str, str] = {}  # bearer token -> user name (TokenReview)
+        self.metrics_readers: set[str] = set()  # users allowed `get /metrics` (SubjectAccessReview)
         self.objects: dict[str, dict] = {}  # full path -> object
         self.rv = 100
         self.watchers: dict[str, list[asyncio.Queue]] = {}  # collection path -> queues
@@ -105,6 +112,21 @@ class FakeKube:
     async def handle(self, request: web.Request) -> web.StreamResponse:
         path, method = request.path, request.method
         self.requests.append((method, path))
+        if self.token is not None and request.headers.get("Authorization") != f"Bearer {self.token}":
+            return web.json_response({"kind": "Status", "reason": "Unauthorized", "code": 401}, status=401)
+        if method == "POST" and path == "/apis/authentication.k8s.io/v1/tokenreviews":
+            body = await request.json()
+            user = self.users.get(body.get("spec", {}).get("token", ""))
+            body["status"] = ({"authenticated": True, "user": {"username": user, "groups": ["system:authenticated"]}}
+                              if user else {"authenticated": False})
+            return web.json_response(body, status=201)
+        if method == "POST" and path == "/apis/authorization.k8s.io/v1/subjectaccessreviews":
+            body = await request.json()
+            spec = body.get("spec", {})
+            nra = spec.get("nonResourceAttributes", {})
+            ok = spec.get("user") in self.metrics_readers and nra == {"path": "/metrics", "verb": "get"}
+            body["status"] = {"allowed": bool(ok)}
+            return web.json_response(body, status=201)
         if method == "GET" and request.query.get("watch") == "true":
             return await self._watch(request)
         if method == "GET":
@@ -201,7 +223,13 @@ class FakeKube:
                 app.router.add_route("*", "/{tail:.*}", self.handle)
                 self.runner = web.AppRunner(app, access_log=None)
                 await self.runner.setup()
-                site = web.TCPSite(self.runner, "127.0.0.1", 0)
+                ctx = None
+                if self.tls:
+                    import ssl
+
+                    ctx = ssl.SSLContext(ssl.PROTOCOL_TLS_SERVER)
+                    ctx.load_cert_chain(*self.tls)
+                site = web.TCPSite(self.runner, "127.0.0.1", 0, ssl_context=ctx)
                 await site.start()
                 self.port = self.runner.addresses[0][1]
                 ready.set()
@@ -216,7 +244,7 @@ class FakeKube:
 
     @property
     def url(self) -> str:
-        return f"http://127.0.0.1:{self.port}"
+        return f"{'https' if self.tls else 'http'}://127.0.0.1:{self.port}"
 
     def stop(self) -> None:
         if self.loop is None:

@@ -257,6 +257,21 @@ def test_operator_kustomize_tree_is_consistent():
         assert f'"{flag}"' in src, f"operator has no flag {flag}"
     assert manager["args"][0] == "run" and manager["livenessProbe"]["httpGet"]["path"] == "/healthz"
     assert dep["spec"]["template"]["spec"]["serviceAccountName"] == "controller-manager"
+    # the manager is alone in its pod and finds the API server itself (no proxy sidecar, no --api)
+    assert len(dep["spec"]["template"]["spec"]["containers"]) == 1 and "--api" not in manager["args"]
+    # the secured metrics port: port, Service, the roles for the reviews and for scrapers, the monitor
+    assert ":8443" in manager["args"] and {"name": "https", "containerPort": 8443} in manager["ports"]
+    svc = yaml.safe_load((cfg / "default" / "metrics_service.yaml").read_text())
+    assert svc["spec"]["ports"][0]["targetPort"] == 8443
+    auth = yaml.safe_load((cfg / "rbac" / "metrics_auth_role.yaml").read_text())
+    assert {r["resources"][0] for r in auth["rules"]} == {"tokenreviews", "subjectaccessreviews"}
+    reader = yaml.safe_load((cfg / "rbac" / "metrics_reader_role.yaml").read_text())
+    assert reader["rules"] == [{"nonResourceURLs": ["/metrics"], "verbs": ["get"]}]
+    mon = yaml.safe_load((cfg / "prometheus" / "monitor.yaml").read_text())
+    assert mon["spec"]["endpoints"][0]["scheme"] == "https" and mon["spec"]["endpoints"][0]["port"] == "https"
+    for patch in yaml.safe_load((cfg / "default" / "cert_metrics_manager_patch.yaml").read_text()):
+        if patch["path"].endswith("/args/-"):
+            assert f'"{patch["value"].split("=")[0]}"' in src
     role = yaml.safe_load((cfg / "rbac" / "role.yaml").read_text())
     granted = {(g, r) for rule in role["rules"] for g in rule["apiGroups"] for r in rule["resources"]}
     for need in [("apps", "deployments"), ("", "services"), ("", "persistentvolumeclaims"),

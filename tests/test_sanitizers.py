@@ -3,6 +3,7 @@ AddressSanitizer+UBSan and with ThreadSanitizer and must finish clean.  (GPU cod
 a sanitizer on the test machines; its checks are the numerics tests in test_kernels_gpu.py.)"""
 
 import os
+import random
 import shutil
 import subprocess
 from pathlib import Path
@@ -23,7 +24,7 @@ def test_routercore_selftest_under_sanitizer(tmp_path, name, flags):
         pytest.skip("no g++")
     exe = tmp_path / f"selftest-{name}"
     build = subprocess.run([gxx, "-std=c++17", "-O1", "-g", *flags, "-I", str(ROOT / "csrc"), *SRC,
-                            "-o", str(exe), "-lpthread"], capture_output=True, text=True)
+                            "-o", str(exe), *libs, "-lpthread"], capture_output=True, text=True)
     if build.returncode != 0 and "cannot find" in build.stderr:
         pytest.skip(f"sanitizer runtime not installed: {build.stderr.splitlines()[-1]}")
     assert build.returncode == 0, build.stderr
@@ -41,14 +42,14 @@ SAN_ENV = {"ASAN_OPTIONS": "detect_leaks=0:abort_on_error=1", "UBSAN_OPTIONS": "
            "TSAN_OPTIONS": "halt_on_error=1"}
 
 
-def _build(tmp_path, name, sources, flags, include=("csrc",)):
+def _build(tmp_path, name, sources, flags, include=("csrc",), libs=()):
     gxx = shutil.which("g++")
     if gxx is None:
         pytest.skip("no g++")
     exe = tmp_path / name
     inc = [x for d in include for x in ("-I", str(ROOT / d))]
     build = subprocess.run([gxx, "-std=c++17", "-O1", "-g", *flags, *inc, *[str(ROOT / s) for s in sources],
-                            "-o", str(exe), "-lpthread"], capture_output=True, text=True)
+                            "-o", str(exe), *libs, "-lpthread"], capture_output=True, text=True)
     if build.returncode != 0 and "cannot find" in build.stderr:
         pytest.skip(f"sanitizer runtime not installed: {build.stderr.splitlines()[-1]}")
     assert build.returncode == 0, build.stderr
@@ -253,3 +254,84 @@ def test_operator_under_asan_ubsan_with_a_hostile_api_server(tmp_path):
                 proc.kill()
         kube.stop()
     _clean(proc.stderr.read())
+
+
+def test_operator_tls_paths_under_asan_ubsan(tmp_path):
+    """The TLS side of the operator, sanitizer-built: the API server over https with the service
+    account's CA bundle and token, and the secured metrics port fed what a port on the pod network
+    gets: plain-text requests, a connection that stops in the middle of the handshake, random
+    bytes, a token the API server does not know, and proper scrapes in between."""
+    import socket
+    import ssl
+    import sys
+    import time
+    import urllib.error
+    import urllib.request
+
+    if shutil.which("openssl") is None:
+        pytest.skip("needs the openssl tool to make certificates")
+    sys.path.insert(0, str(ROOT / "tests"))
+    from fake_k8s import FakeKube
+
+    exe = _build(tmp_path, "operator-tls-asan", ["csrc/operator/operator_main.cpp"], SAN_FLAGS + ["-DVHTTP_TLS"],
+                 libs=("-lssl", "-lcrypto"))
+    crt, key = tmp_path / "tls.crt", tmp_path / "tls.key"
+    subprocess.run(["openssl", "req", "-x509", "-newkey", "rsa:2048", "-nodes", "-keyout", str(key), "-out", str(crt), "-days", "2",
+                    "-subj", "/CN=127.0.0.1", "-addext", "subjectAltName=IP:127.0.0.1"], check=True, capture_output=True)
+    kube = FakeKube(tls=(str(crt), str(key)), token="sa").start()
+    kube.users = {"prom": "prometheus"}
+    kube.metrics_readers = {"prometheus"}
+    sa = tmp_path / "sa"
+    sa.mkdir()
+    (sa / "token").write_text("sa")
+    shutil.copy(crt, sa / "ca.crt")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        mport = s.getsockname()[1]
+    env = dict(_san_env(), VPSA_SA_DIR=str(sa), KUBERNETES_SERVICE_HOST="127.0.0.1", KUBERNETES_SERVICE_PORT=str(kube.port))
+    proc = subprocess.Popen([str(exe), "run", "--namespace", "default", "--interval", "1", "--health-port", "0",
+                             "--metrics-bind-address", f"127.0.0.1:{mport}", "--metrics-cert-path", str(tmp_path)],
+                            stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True, env=env)
+
+    def scrape(token):
+        req = urllib.request.Request(f"https://127.0.0.1:{mport}/metrics", headers={"Authorization": f"Bearer {token}"})
+        try:
+            with urllib.request.urlopen(req, timeout=10, context=ssl.create_default_context(cafile=str(crt))) as r:
+                return r.status
+        except urllib.error.HTTPError as e:
+            return e.code
+
+    try:
+        t0 = time.time()
+        while time.time() - t0 < 20:
+            assert proc.poll() is None, proc.stderr.read()[-4000:]
+            try:
+                if scrape("prom") == 200:
+                    break
+            except OSError:
+                time.sleep(0.1)
+        else:
+            raise AssertionError("metrics port never answered")
+        rng = random.Random(7)
+        for i in range(40):
+            with socket.create_connection(("127.0.0.1", mport), timeout=5) as c:
+                kind = i % 4
+                if kind == 0:
+                    c.sendall(b"GET /metrics HTTP/1.1\r\nHost: x\r\n\r\n")  # plain text to a TLS port
+                elif kind == 1:
+                    c.sendall(bytes([0x16, 0x03, 0x01, 0x02, 0x00, 0x01, 0x00]))  # a ClientHello that never continues
+                elif kind == 2:
+                    c.sendall(bytes(rng.randrange(256) for _ in range(rng.randrange(1, 3000))))
+                # kind 3: connect and say nothing
+        assert scrape("unknown") == 401
+        assert scrape("prom") == 200
+        assert any(p.endswith("/vllmruntimes") for _m, p in kube.requests), "the control loop reached the API server over TLS"
+    finally:
+        proc.terminate()
+        try:
+            proc.wait(10)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+        err = proc.stderr.read()
+        kube.stop()
+    _clean(err)

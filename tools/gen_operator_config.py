@@ -2,8 +2,11 @@
 
 Counterpart of the reference's kubebuilder-generated /root/reference/operator/config/**
 (manager Deployment, RBAC incl. per-CRD admin/editor/viewer roles, leader election, CRD and
-sample kustomizations, network policy).  The manager here is the C++ ``vpsa-operator`` binary
-talking to the API server through a loopback ``kubectl proxy`` sidecar.
+sample kustomizations, metrics Service + auth roles + ServiceMonitor, network policies).  The
+manager is the C++ ``vpsa-operator`` binary alone in its pod: it finds the API server from the pod
+environment, verifies it against the service account's CA bundle, authenticates with the
+service account's token, and serves its metrics over TLS on :8443 to callers the API server
+authenticates and authorizes.
 
     python tools/gen_operator_config.py          # rewrites deploy/operator/config
 """
@@ -76,20 +79,17 @@ def main():
                     "containers": [
                         {"name": "manager", "image": "controller:latest",
                          "command": ["/usr/local/bin/vpsa-operator"],
-                         "args": ["run", "--api", "http://127.0.0.1:8001", "--health-port", "8081",
+                         "args": ["run", "--leader-elect", "--leader-elect-namespace", "$(POD_NAMESPACE)",
+                                  "--health-port", "8081", "--metrics-bind-address", ":8443",
                                   "--gpu-resource", "amd.com/gpu", "--interval", "10"],
-                         "ports": [{"name": "health", "containerPort": 8081}],
+                         "env": [{"name": "POD_NAMESPACE", "valueFrom": {"fieldRef": {"fieldPath": "metadata.namespace"}}}],
+                         "ports": [{"name": "health", "containerPort": 8081}, {"name": "https", "containerPort": 8443}],
+                         "volumeMounts": [], 
                          "livenessProbe": probe("/healthz"), "readinessProbe": probe("/readyz"),
                          "securityContext": {"allowPrivilegeEscalation": False, "capabilities": {"drop": ["ALL"]}},
                          "resources": {"limits": {"cpu": "500m", "memory": "128Mi"},
-                                       "requests": {"cpu": "10m", "memory": "64Mi"}}},
-                        # the operator speaks plain HTTP to the API server through this loopback proxy,
-                        # which adds the pod's service-account credentials
-                        {"name": "kube-api-proxy", "image": "bitnami/kubectl:latest",
-                         "args": ["proxy", "--port=8001", "--address=127.0.0.1"],
-                         "securityContext": {"allowPrivilegeEscalation": False, "capabilities": {"drop": ["ALL"]}},
-                         "resources": {"limits": {"cpu": "200m", "memory": "64Mi"},
-                                       "requests": {"cpu": "10m", "memory": "32Mi"}}}]}}}})
+                                       "requests": {"cpu": "10m", "memory": "64Mi"}}}],
+                    "volumes": []}}}})
     kustomization("manager/kustomization.yaml", ["namespace.yaml", "deployment.yaml"],
                   images=[{"name": "controller", "newName": "vpsa/operator", "newTag": "latest"}])
 
@@ -129,8 +129,25 @@ def main():
         "metadata": {"name": "leader-election-rolebinding", "labels": LABELS},
         "roleRef": {"apiGroup": "rbac.authorization.k8s.io", "kind": "Role", "name": "leader-election-role"},
         "subjects": sa})
+    # the secured metrics port asks the API server who a caller is and what it may do ...
+    write("rbac/metrics_auth_role.yaml", {
+        "apiVersion": "rbac.authorization.k8s.io/v1", "kind": "ClusterRole",
+        "metadata": {"name": "metrics-auth-role", "labels": LABELS},
+        "rules": [{"apiGroups": ["authentication.k8s.io"], "resources": ["tokenreviews"], "verbs": ["create"]},
+                  {"apiGroups": ["authorization.k8s.io"], "resources": ["subjectaccessreviews"], "verbs": ["create"]}]})
+    write("rbac/metrics_auth_role_binding.yaml", {
+        "apiVersion": "rbac.authorization.k8s.io/v1", "kind": "ClusterRoleBinding",
+        "metadata": {"name": "metrics-auth-rolebinding", "labels": LABELS},
+        "roleRef": {"apiGroup": "rbac.authorization.k8s.io", "kind": "ClusterRole", "name": "metrics-auth-role"},
+        "subjects": sa})
+    # ... and this is the role to bind to whoever scrapes (e.g. the Prometheus service account)
+    write("rbac/metrics_reader_role.yaml", {
+        "apiVersion": "rbac.authorization.k8s.io/v1", "kind": "ClusterRole",
+        "metadata": {"name": "metrics-reader", "labels": LABELS},
+        "rules": [{"nonResourceURLs": ["/metrics"], "verbs": ["get"]}]})
     files = ["service_account.yaml", "role.yaml", "role_binding.yaml", "leader_election_role.yaml",
-             "leader_election_role_binding.yaml"]
+             "leader_election_role_binding.yaml", "metrics_auth_role.yaml", "metrics_auth_role_binding.yaml",
+             "metrics_reader_role.yaml"]
     # helper roles for cluster users (not used by the operator itself)
     verbs = {"admin": ["*"], "editor": ["create", "delete", "get", "list", "patch", "update", "watch"],
              "viewer": ["get", "list", "watch"]}
@@ -150,10 +167,56 @@ def main():
         "metadata": {"name": "allow-health-traffic", "namespace": "system", "labels": LABELS},
         "spec": {"podSelector": {"matchLabels": {"control-plane": "controller-manager"}},
                  "policyTypes": ["Ingress"], "ingress": [{"ports": [{"port": 8081, "protocol": "TCP"}]}]}})
-    kustomization("network-policy/kustomization.yaml", ["allow-health-traffic.yaml"])
+    write("network-policy/allow-metrics-traffic.yaml", {
+        "apiVersion": "networking.k8s.io/v1", "kind": "NetworkPolicy",
+        "metadata": {"name": "allow-metrics-traffic", "namespace": "system", "labels": LABELS},
+        "spec": {"podSelector": {"matchLabels": {"control-plane": "controller-manager"}},
+                 "policyTypes": ["Ingress"],
+                 # scrapers live in namespaces labelled metrics=enabled
+                 "ingress": [{"from": [{"namespaceSelector": {"matchLabels": {"metrics": "enabled"}}}],
+                              "ports": [{"port": 8443, "protocol": "TCP"}]}]}})
+    kustomization("network-policy/kustomization.yaml", ["allow-health-traffic.yaml", "allow-metrics-traffic.yaml"])
+
+    # ---- metrics: Service in front of the TLS port, ServiceMonitor for the Prometheus operator
+    write("default/metrics_service.yaml", {
+        "apiVersion": "v1", "kind": "Service",
+        "metadata": {"name": "controller-manager-metrics-service", "namespace": "system",
+                     "labels": {**LABELS, "control-plane": "controller-manager"}},
+        "spec": {"ports": [{"name": "https", "port": 8443, "protocol": "TCP", "targetPort": 8443}],
+                 "selector": {"control-plane": "controller-manager"}}})
+    # with cert-manager: mount the issued secret and point the manager at it (it re-reads the
+    # files when the secret is renewed); without this patch the manager signs its own certificate
+    write("default/cert_metrics_manager_patch.yaml",
+          [{"op": "add", "path": "/spec/template/spec/containers/0/volumeMounts/-",
+            "value": {"mountPath": "/tmp/k8s-metrics-server/metrics-certs", "name": "metrics-certs", "readOnly": True}},
+           {"op": "add", "path": "/spec/template/spec/containers/0/args/-",
+            "value": "--metrics-cert-path=/tmp/k8s-metrics-server/metrics-certs"},
+           {"op": "add", "path": "/spec/template/spec/volumes/-",
+            "value": {"name": "metrics-certs",
+                      "secret": {"secretName": "metrics-server-cert", "optional": False,
+                                 "items": [{"key": k, "path": k} for k in ("ca.crt", "tls.crt", "tls.key")]}}}],
+          header="JSON patch for the manager Deployment; enable it in kustomization.yaml (patches:) once\n"
+                 "cert-manager issues the secret metrics-server-cert.")
+    write("prometheus/monitor.yaml", {
+        "apiVersion": "monitoring.coreos.com/v1", "kind": "ServiceMonitor",
+        "metadata": {"name": "controller-manager-metrics-monitor", "namespace": "system",
+                     "labels": {**LABELS, "control-plane": "controller-manager"}},
+        "spec": {"endpoints": [{"path": "/metrics", "port": "https", "scheme": "https",
+                                "bearerTokenFile": "/var/run/secrets/kubernetes.io/serviceaccount/token",
+                                "tlsConfig": {"insecureSkipVerify": True}}],
+                 "selector": {"matchLabels": {"control-plane": "controller-manager"}}}})
+    write("prometheus/monitor_tls_patch.yaml",
+          [{"op": "replace", "path": "/spec/endpoints/0/tlsConfig",
+            "value": {"serverName": "SERVICE_NAME.SERVICE_NAMESPACE.svc", "insecureSkipVerify": False,
+                      "ca": {"secret": {"name": "metrics-server-cert", "key": "ca.crt"}},
+                      "cert": {"secret": {"name": "metrics-server-cert", "key": "tls.crt"}},
+                      "keySecret": {"name": "metrics-server-cert", "key": "tls.key"}}}],
+          header="JSON patch for the ServiceMonitor when the metrics certificate comes from cert-manager:\n"
+                 "verify the server against the issuing CA instead of skipping verification.")
+    kustomization("prometheus/kustomization.yaml", ["monitor.yaml"])
 
     # ---- default overlay
-    kustomization("default/kustomization.yaml", ["../crd", "../rbac", "../manager"],
+    kustomization("default/kustomization.yaml", ["../crd", "../rbac", "../manager", "metrics_service.yaml"],
                   namespace="production-stack-system", namePrefix="production-stack-",
                   labels=[{"pairs": {"app.kubernetes.io/part-of": "vllm-production-stack-amd"}}])
 

@@ -50,7 +50,7 @@ SOURCE_FLAGS = {
 # standalone executables: name -> (kind, sources, flags)
 BINARIES = {
     "vpsa-picker": ("cxx", ["routercore/picker_service.cpp", "routercore/routercore.cpp"], ["-lpthread"]),
-    "vpsa-operator": ("cxx", ["operator/operator_main.cpp"], ["-lpthread"]),
+    "vpsa-operator": ("cxx", ["operator/operator_main.cpp"], ["-DVHTTP_TLS", "-lssl", "-lcrypto", "-lpthread"]),
 }
 
 

@@ -702,9 +702,16 @@ def render_lora(values: dict, release: str, namespace: str) -> list[dict]:
         name = f"{release}-lora-controller"
         labels = {"app.kubernetes.io/component": "lora-controller", "helm-release-name": release}
         img = lc.get("image") or {}
-        args = ["run", "--api", "http://127.0.0.1:8001", "--namespace", namespace,
-                "--gpu-resource", DEFAULT_GPU_RESOURCE, "--health-port", "8081",
-                *[str(a) for a in lc.get("extraArgs") or []]]
+        metrics = lc.get("metrics") or {}
+        cert_dir = "/tmp/k8s-metrics-server/metrics-certs"
+        # no --api: inside the pod the operator finds the API server from the environment and
+        # authenticates with its service account (CA bundle + token from the projected volume)
+        args = ["run", "--namespace", namespace, "--gpu-resource", DEFAULT_GPU_RESOURCE, "--health-port", "8081"]
+        if metrics.get("enabled"):
+            args += ["--metrics-bind-address", ":8443"]
+            if metrics.get("certSecret"):
+                args += ["--metrics-cert-path", cert_dir]
+        args += [str(a) for a in lc.get("extraArgs") or []]
         ctr: dict[str, Any] = {
             "name": "manager", "image": f"{img.get('repository', 'vpsa/operator')}:{img.get('tag', 'latest')}",
             "imagePullPolicy": img.get("pullPolicy", "IfNotPresent"),
@@ -716,13 +723,12 @@ def render_lora(values: dict, release: str, namespace: str) -> list[dict]:
                                "initialDelaySeconds": 5, "periodSeconds": 10}}
         if lc.get("resources"):
             ctr["resources"] = copy.deepcopy(lc["resources"])
-        # the operator speaks plain HTTP; the API-server hop (TLS + service-account token) is a
-        # kubectl-proxy sidecar bound to loopback
-        proxy = {"name": "kube-api-proxy", "image": lc.get("proxyImage", "bitnami/kubectl:latest"),
-                 "command": ["kubectl", "proxy", "--port=8001", "--address=127.0.0.1"]}
-        pod_spec: dict[str, Any] = {"serviceAccountName": name, "containers": [ctr, proxy],
+        pod_spec: dict[str, Any] = {"serviceAccountName": name, "containers": [ctr],
                                     "securityContext": copy.deepcopy(lc.get("podSecurityContext") or {}),
                                     "terminationGracePeriodSeconds": 10}
+        if metrics.get("enabled") and metrics.get("certSecret"):
+            ctr["volumeMounts"] = [{"name": "metrics-certs", "mountPath": cert_dir, "readOnly": True}]
+            pod_spec["volumes"] = [{"name": "metrics-certs", "secret": {"secretName": metrics["certSecret"]}}]
         for k in ("nodeSelector", "affinity", "tolerations", "imagePullSecrets"):
             if lc.get(k):
                 pod_spec[k] = copy.deepcopy(lc[k])
@@ -744,6 +750,10 @@ def render_lora(values: dict, release: str, namespace: str) -> list[dict]:
             {"apiGroups": ["coordination.k8s.io"], "resources": ["leases"],
              "verbs": ["get", "list", "watch", "create", "update", "patch", "delete"]},
             {"apiGroups": [""], "resources": ["events"], "verbs": ["create", "patch"]}]
+        if metrics.get("enabled"):  # the secured metrics port reviews its callers' tokens
+            crd_rules += [
+                {"apiGroups": ["authentication.k8s.io"], "resources": ["tokenreviews"], "verbs": ["create"]},
+                {"apiGroups": ["authorization.k8s.io"], "resources": ["subjectaccessreviews"], "verbs": ["create"]}]
         out += [
             {"apiVersion": "v1", "kind": "ServiceAccount", "metadata": _meta(name, namespace, labels)},
             {"apiVersion": "rbac.authorization.k8s.io/v1", "kind": "ClusterRole",
@@ -758,10 +768,13 @@ def render_lora(values: dict, release: str, namespace: str) -> list[dict]:
                                                 **({"annotations": lc["podAnnotations"]}
                                                    if lc.get("podAnnotations") else {})},
                                    "spec": pod_spec}}}]
-        if (lc.get("metrics") or {}).get("enabled"):
+        if metrics.get("enabled"):
+            out.append({"apiVersion": "rbac.authorization.k8s.io/v1", "kind": "ClusterRole",
+                        "metadata": _meta(f"{name}-metrics-reader", None, labels),
+                        "rules": [{"nonResourceURLs": ["/metrics"], "verbs": ["get"]}]})
             out.append({"apiVersion": "v1", "kind": "Service",
                         "metadata": _meta(f"{name}-metrics", namespace, labels),
-                        "spec": {"selector": labels, "ports": [{"name": "health", "port": 8081, "targetPort": 8081}]}})
+                        "spec": {"selector": labels, "ports": [{"name": "https", "port": 8443, "targetPort": 8443}]}})
     return out
 
 
