@@ -60,12 +60,7 @@ case "${1:-}" in
     ;;
   smoke) smoke_test ;;
   cleanup)
-    need az
-    if az aks get-credentials --resource-group "$RG" --name "$CLUSTER" --overwrite-existing 2>/dev/null; then
-      uninstall_stack
-    fi
-    az group delete --name "$RG" --yes --no-wait
-    echo "resource group $RG is being deleted (az group show -n $RG to follow)"
+    exec "$here/clean_up.sh" "$RG" "$CLUSTER"
     ;;
   *) echo "usage: $0 setup <values.yaml> | status | smoke | cleanup" >&2; exit 2 ;;
 esac

@@ -59,15 +59,7 @@ case "${1:-}" in
     ;;
   smoke) smoke_test ;;
   cleanup)
-    need gcloud
-    if gcloud container clusters get-credentials "$CLUSTER" --zone "$ZONE" 2>/dev/null; then
-      uninstall_stack
-      # dynamically provisioned disks outlive the cluster unless their claims are gone first
-      kubectl get pv -o name 2>/dev/null | xargs -r kubectl delete --wait=false || true
-    fi
-    gcloud container clusters delete "$CLUSTER" --zone "$ZONE" --quiet
-    left=$(gcloud compute disks list --filter="name~^gke-$CLUSTER AND -users:*" --format="value(name)" || true)
-    [ -n "$left" ] && echo "unattached disks left behind: $left (gcloud compute disks delete …)"
+    exec "$here/clean_up.sh" "$CLUSTER" "$ZONE"
     ;;
   *) echo "usage: $0 setup <values.yaml> | setup-cpu | status | smoke | cleanup" >&2; exit 2 ;;
 esac

@@ -17,6 +17,10 @@ resource "azurerm_kubernetes_cluster" "aks" {
   }
   identity { type = "SystemAssigned" }
   network_profile { network_plugin = "azure" }
+  linux_profile {
+    admin_username = var.node_admin_user
+    ssh_key { key_data = tls_private_key.node_ssh.public_key_openssh }
+  }
 }
 
 # GPU pool: tainted so that only workloads that tolerate sku=gpu land there.  AKS installs no

@@ -3,6 +3,7 @@ terraform {
   required_providers {
     azurerm = { source = "hashicorp/azurerm", version = "~> 3.110" }
     local   = { source = "hashicorp/local", version = "~> 2.5" }
+    tls     = { source = "hashicorp/tls", version = "~> 4.0" }
   }
 }
 

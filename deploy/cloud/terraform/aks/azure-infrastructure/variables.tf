@@ -37,3 +37,8 @@ variable "kubeconfig_path" {
   type        = string
   default     = "../kubeconfig"
 }
+variable "node_admin_user" {
+  description = "admin user on the nodes; its SSH key is made in ssh.tf"
+  type        = string
+  default     = "azureuser"
+}

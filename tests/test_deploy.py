@@ -362,8 +362,19 @@ def test_cloud_scripts_parse_and_share_the_common_tail():
         assert r.returncode == 0, (p, r.stderr)
     for cloud in ("aws", "azure", "gcp"):
         text = (CLOUD / cloud / "entry_point.sh").read_text()
-        for step in ("need ", "wait_nodes_ready", "install_stack", "smoke_test", "uninstall_stack" if cloud != "aws" else "clean_up.sh"):
+        for step in ("need ", "wait_nodes_ready", "install_stack", "smoke_test", "clean_up.sh"):
             assert step in text, (cloud, step)
+        # each cloud's clean-up walks its dependency chain: release and volumes before the cluster
+        clean = (CLOUD / cloud / "clean_up.sh").read_text()
+        assert clean.index("uninstall_stack") < clean.index({"aws": "eksctl delete cluster", "azure": "az aks delete",
+                                                               "gcp": "gcloud container clusters delete"}[cloud]), cloud
+    # the device plugin manifest the scripts apply: both DaemonSets tolerate the GPU pools' taint
+    docs = [d for d in yaml.safe_load_all((ROOT / "deploy" / "manifests" / "amd-device-plugin-ds.yaml").read_text()) if d]
+    daemonsets = [d for d in docs if d["kind"] == "DaemonSet"]
+    assert len(daemonsets) == 2
+    for ds in daemonsets:
+        assert {"operator": "Exists"} in ds["spec"]["template"]["spec"]["tolerations"]
+    assert "amd-device-plugin-ds.yaml" in (ROOT / "utils" / "init-amd-gpu-setup-k8s.sh").read_text()
     # every Terraform root module declares its providers and formats as HCL blocks that balance
     for tf in CLOUD.glob("terraform/**/*.tf"):
         body = tf.read_text()
