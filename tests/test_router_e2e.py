@@ -111,6 +111,15 @@ def test_error_shapes():
                 assert "X-Request-Id" in r.headers
             st, data, _ = await s.chat(model="nope")
             assert st == 400 and b"not found or vLLM engine is sleeping" in data
+            # demand nobody could serve is counted per model (what a scale-from-zero trigger queries);
+            # the model name is client input, so only a bounded number of names get their own series
+            for i in range(70):
+                await s.chat(model=f"made-up-{i}")
+            async with s.http.get(s.url + "/metrics") as r:
+                text = await r.text()
+            assert 'vllm:router_unroutable_requests_total{model="nope"}' in text
+            series = [ln for ln in text.splitlines() if ln.startswith("vllm:router_unroutable_requests_total{")]
+            assert len(series) <= 65 and any('model="other"' in ln for ln in series)
             async with s.http.post(s.url + "/v1/chat/completions", data=b"{bad") as r:
                 assert r.status == 400
     run(go())

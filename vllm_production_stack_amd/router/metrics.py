@@ -8,7 +8,7 @@ from __future__ import annotations
 import time
 
 import psutil
-from prometheus_client import CollectorRegistry, Gauge, generate_latest
+from prometheus_client import CollectorRegistry, Counter, Gauge, generate_latest
 
 REGISTRY = CollectorRegistry()
 
@@ -34,6 +34,20 @@ router_cpu = Gauge("router_cpu_usage_percent", "CPU usage percent", registry=REG
 router_mem = Gauge("router_memory_usage_percent", "Memory usage percent", registry=REGISTRY)
 router_disk = Gauge("router_disk_usage_percent", "Disk usage percent", registry=REGISTRY)
 routing_latency = Gauge("vllm:router_decision_seconds", "Last routing decision latency", registry=REGISTRY)
+# demand that found no replica (none deployed, all asleep, scaled to zero): the signal a
+# scale-from-zero trigger needs, since engine gauges do not exist while there is no engine
+unroutable_requests = Counter("vllm:router_unroutable_requests", "Requests for a model that no awake engine serves",
+                              ["model"], registry=REGISTRY)
+
+
+def count_unroutable(model: str, max_series: int = 64) -> None:
+    """The model label is client input: bounded in length, and in how many distinct values get a
+    series of their own (the rest are counted under ``other``)."""
+    model = model[:128]
+    known = unroutable_requests._metrics
+    if (model,) not in known and len(known) >= max_series:
+        model = "other"
+    unroutable_requests.labels(model=model).inc()
 
 
 def refresh(state) -> None:

@@ -178,6 +178,9 @@ async def _route_general(state, request: web.Request, endpoint: str, span) -> we
     else:
         candidates = [e for e in endpoints if requested_model in e.model_names and not e.sleep]
     if not candidates:
+        from . import metrics
+
+        metrics.count_unroutable(str(requested_model))
         return _json_error(
             400, f"Model {requested_model} not found or vLLM engine is sleeping.", request_id)
 
