@@ -397,6 +397,147 @@ def _workload_literals(objs):
     return flags, envs
 
 
+_ACTION_ONLY = re.compile(r"^{{-?\s*(if|else|end|range|with|define|include|toYaml|template|\$[\w]+\s*:?=)\b.*}}$")
+_FLAG = re.compile(r"(?<![\w-])--[a-z][a-z0-9_-]*")
+
+
+def _template_sites(text: str) -> set[tuple]:
+    """Where each literal of a chart template sits: (kind, containers|initContainers, container
+    name, command|args|env, literal) for every command-line flag and environment variable name.
+
+    The Go templates cannot be rendered here, but their non-action lines are YAML whose
+    indentation is the structure: actions that stand alone on a line are dropped, inline actions
+    become a placeholder, and the path of a line is the chain of less-indented keys above it.  A
+    container name that is itself templated reads as ``*``."""
+    text = re.sub(r"{{-?\s*/\*.*?\*/\s*-?}}", "", text, flags=re.S)
+    sites: set[tuple] = set()
+    for doc in re.split(r"(?m)^---\s*$", text):
+        kind = None
+        stack: list[tuple[int, str]] = []  # (indent, key)
+        container: dict[int, str] = {}  # indent of a "- " item under (init)containers -> its name
+        for raw in doc.splitlines():
+            line = raw.rstrip()
+            body = line.strip()
+            if not body or _ACTION_ONLY.match(body) or body.startswith("#"):
+                continue
+            indent = len(line) - len(line.lstrip())
+            item = body.startswith("- ")
+            content = body[2:].lstrip() if item else body
+            key_indent = indent + 2 if item else indent
+            while stack and stack[-1][0] >= (indent if item else key_indent):
+                stack.pop()
+            for ind in [i for i in container if i > indent or (i == indent and item)]:
+                del container[ind]
+            m = re.match(r"([A-Za-z_][\w.-]*):(?:\s+(.*))?$", content)
+            keys = [k for _, k in stack]
+            if indent == 0 and m and m.group(1) == "kind":
+                kind = "*" if "{{" in (m.group(2) or "") else (m.group(2) or "").strip()
+            section = next((k for k in reversed(keys) if k in ("containers", "initContainers")), None)
+            if section and item and m and m.group(1) == "name" and keys and keys[-1] == section:
+                container[indent] = "*" if "{{" in (m.group(2) or "") else (m.group(2) or "").strip().strip('"')
+            cname = container[max(container)] if container else None
+            field = None
+            if section and cname is not None:
+                after = keys[len(keys) - 1 - keys[::-1].index(section) + 1:]
+                field = (m.group(1) if m and not after else after[0] if after else None)
+            if field in ("command", "args"):
+                for flag in _FLAG.findall(content):  # string literals inside an inline action count too
+                    sites.add((kind, section, cname, "command/args", flag))
+            if field == "env" and item and m and m.group(1) == "name" and "{{" not in (m.group(2) or ""):
+                sites.add((kind, section, cname, "env", (m.group(2) or "").strip().strip('"')))
+            if m:
+                stack.append((key_indent, m.group(1)))
+    return sites
+
+
+def _rendered_sites(objs) -> set[tuple]:
+    out = set()
+    for o in objs:
+        if o["kind"] not in ("Deployment", "StatefulSet"):
+            continue
+        pod = o["spec"]["template"]["spec"]
+        for section in ("containers", "initContainers"):
+            for c in pod.get(section) or []:
+                for word in list(c.get("command") or []) + list(c.get("args") or []):
+                    for flag in _FLAG.findall(str(word)):
+                        out.add((o["kind"], section, c["name"], "command/args", flag))
+                for e in c.get("env") or []:
+                    out.add((o["kind"], section, c["name"], "env", e["name"]))
+    return out
+
+
+def test_template_site_parser_on_a_known_snippet():
+    sites = _template_sites("""
+apiVersion: apps/v1
+kind: Deployment
+spec:
+  template:
+    spec:
+      initContainers:
+        - name: {{ default "init" .name }}
+          command: ["sh", "-c", "download --from x"]
+      containers:
+        - name: vllm
+          {{- if .Values.x }}
+          command:
+            - vpsa-engine
+            - "--port"
+            {{- with .y }}
+            - "--seed"
+            - {{ . | quote }}
+            {{- end }}
+          {{- end }}
+          env:
+            - name: HF_HOME
+              value: /data
+            - name: {{ .custom }}
+              value: "--not-a-flag-site"
+          ports:
+            - name: container-port
+        - name: sidecar
+          env:
+            - name: PORT
+              value: "1"
+      volumes:
+        - name: shm
+---
+kind: Service
+spec:
+  ports:
+    - name: http
+""")
+    assert sites == {
+        ("Deployment", "initContainers", "*", "command/args", "--from"),
+        ("Deployment", "containers", "vllm", "command/args", "--port"),
+        ("Deployment", "containers", "vllm", "command/args", "--seed"),
+        ("Deployment", "containers", "vllm", "env", "HF_HOME"),
+        ("Deployment", "containers", "sidecar", "env", "PORT"),
+    }
+
+
+@pytest.mark.parametrize("path", EXAMPLES, ids=lambda p: p.stem)
+def test_chart_puts_every_flag_and_env_where_the_renderer_puts_it(path):
+    """The chart and the Python renderer implement one contract twice, and no `helm` binary exists
+    here to render the Go templates.  So the templates are read structurally: every flag and every
+    environment variable the renderer emits for an example must be spelled out in a chart
+    template under the same workload kind, the same container and the same field (a variable
+    under the sidecar instead of the engine, or a flag in the init container, fails), unless it
+    comes straight from the example's own values (extra args, user env)."""
+    chart: set[tuple] = set()
+    for tpl in (ROOT / "deploy/helm/templates").glob("*.yaml"):
+        chart |= _template_sites(tpl.read_text())
+    own = path.read_text()
+    missing = []
+    for kind, section, cname, field, literal in sorted(_rendered_sites(_objs(path))):
+        if literal in own:
+            continue
+        if not any((kind, section, n, field, literal) in chart for n in (cname, "*")):
+            elsewhere = sorted({(k, s_, n, f) for k, s_, n, f, lit in chart if lit == literal})
+            missing.append(f"{literal} under {kind}/{section}[{cname}]/{field}" +
+                           (f" (the chart has it under {elsewhere})" if elsewhere else " (nowhere in the chart)"))
+    assert not missing, f"{path.name}: " + "; ".join(missing)
+
+
 @pytest.mark.parametrize("path", EXAMPLES, ids=lambda p: p.stem)
 def test_chart_names_every_flag_and_env_the_renderer_emits(path):
     """The chart and the Python renderer implement one contract twice.  No `helm` binary exists
