@@ -107,3 +107,29 @@ def test_tp2_graph_decode_matches_eager_and_runs_on_every_rank():
     assert d_graph[2] == d_eager[2], (d_graph[2], d_eager[2])
     assert d_graph[3] == d_eager[3]
     assert all(len(o) == SP.max_tokens for o in d_graph[2])
+
+
+def test_pipeline_stages_on_the_hip_kernels_hand_over_through_the_host():
+    """Two pipeline stages share the card (gloo default group): the hand-over between stages must
+    wait for the producing kernels and land before the consuming ones, which gloo does not do by
+    itself for a device pointer.  The rehearsal script generates through both stages and compares
+    with one stage holding every layer."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, VPSA_TP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          str(root / "benchmarks" / "pp_rehearsal.py"), "--pp", "2", "--model", "tiny-llama-gqa",
+                          "--prompt-len", "300", "--max-tokens", "8", "--num-gpu-blocks", "96"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    line = next((ln for ln in run.stdout.splitlines() if ln.startswith("{")), None)
+    assert run.returncode == 0 and line, run.stderr[-3000:]
+    res = json.loads(line)
+    assert res["device"] == "cuda" and res["agrees"], res
+    assert [s["layers"] for s in res["stages"]] == [[0, 2], [2, 3]]

@@ -114,6 +114,8 @@ def set_replica(r: ReplicaGroup) -> None:
 
 
 def reset_parallel_state() -> None:
+    global _PP_HOST_STAGED
+    _PP_HOST_STAGED = None
     set_tp(TPGroup())
     set_pp(PPGroup())
     set_replica(ReplicaGroup())
@@ -246,11 +248,31 @@ def tp_all_gather_last_dim(x: torch.Tensor) -> torch.Tensor:
     return out.view(tp.size, lead, x.shape[1]).movedim(0, 1).reshape(lead, tp.size * x.shape[1])
 
 
+def _pp_host_staged() -> bool:
+    """GPU stages over a gloo default group (ranks rehearsing on fewer cards than ranks): gloo takes
+    a device pointer as it is and reads or writes it from the host without regard to the stream
+    that produces or consumes it, so the hand-over goes through host memory explicitly."""
+    global _PP_HOST_STAGED
+    if _PP_HOST_STAGED is None:
+        _PP_HOST_STAGED = dist.get_backend() == "gloo"
+    return _PP_HOST_STAGED
+
+
+_PP_HOST_STAGED: "bool | None" = None
+
+
 def pp_send(x: torch.Tensor, dst: int) -> None:
+    if x.is_cuda and _pp_host_staged():
+        dist.send(x.contiguous().cpu(), dst=dst)  # .cpu() waits for the kernels that wrote x
+        return
     dist.send(x.contiguous(), dst=dst)
 
 
 def pp_recv(shape, dtype: torch.dtype, device: torch.device, src: int) -> torch.Tensor:
+    if device.type == "cuda" and _pp_host_staged():
+        h = torch.empty(shape, dtype=dtype)
+        dist.recv(h, src=src)
+        return h.to(device)
     t = torch.empty(shape, dtype=dtype, device=device)
     dist.recv(t, src=src)
     return t
