@@ -92,7 +92,7 @@ def parse() -> argparse.Namespace:
                     help="rounds of the second phase in the reference's own configuration (0 = skip)")
     ap.add_argument("--reference-users-per-gpu", type=int, default=15)
     ap.add_argument("--reference-offload-gb", type=float, default=45.0)
-    ap.add_argument("--open-loop-seconds", type=int, default=30,
+    ap.add_argument("--open-loop-seconds", type=int, default=100,
                     help="after the rounds of the reference-configuration phase: the reference's own "
                          "open-loop procedure (QPS-paced arrivals, users joining over time) for this long; 0 = skip")
     ap.add_argument("--open-loop-qps-per-gpu", type=float, default=1.1,

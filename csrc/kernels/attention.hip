@@ -35,7 +35,8 @@ __device__ __forceinline__ bf16x8 lds_read_frag(const char* lds, int byte_off) {
 // ---------------------------------------------------------------------------------
 // Prefill / chunked prefill / prefix-hit prefill.
 //   q, out       [tokens, n_q * 128] bf16 with explicit row strides
-//   tile_seq[i], tile_q0[i]: work list, one entry per (sequence, query tile of QT rows)
+//   tile_seq[i], tile_q0[i]: work list, one entry per (sequence, query tile of QT rows);
+//                            tile_seq[i] < 0 marks an unused entry
 //   cu_q[s]      first row of sequence s in q/out; q_len = cu_q[s+1] - cu_q[s]
 //   ctx_lens[s]  keys visible to the LAST query row of s (cached prefix + new tokens; the
 //                new tokens' K/V are already in the cache when this kernel runs)
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
   const int qsub = wave / GP;
 
   const int seq = tile_seq[blockIdx.x];
+  if (seq < 0) return;  // padding of a fixed-size work list (captured graphs): the whole workgroup leaves
   const int q0 = tile_q0[blockIdx.x];
   const int row0 = cu_q[seq];
   const int q_len = cu_q[seq + 1] - row0;
@@ -291,6 +293,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel_v2(
   const int qsub = wave / GP;
 
   const int seq = tile_seq[bx];
+  if (seq < 0) return;  // padding of a fixed-size work list (captured graphs): the whole workgroup leaves
   const int q0 = tile_q0[bx];
   const int row0 = cu_q[seq];
   const int q_len = cu_q[seq + 1] - row0;
@@ -551,6 +554,7 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v3(
   const int head = kvh * G + (by % groups_per_kv) * 4 + wave;
 
   const int seq = tile_seq[bx];
+  if (seq < 0) return;  // padding of a fixed-size work list (captured graphs): the whole workgroup leaves
   const int q0 = tile_q0[bx];
   const int row0 = cu_q[seq];
   const int q_len = cu_q[seq + 1] - row0;
@@ -1051,6 +1055,7 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
   const int head = kvh * G + (by % groups_per_kv) * 4 + wave;
 
   const int seq = tile_seq[bx];
+  if (seq < 0) return;  // padding of a fixed-size work list (captured graphs): the whole workgroup leaves
   const int q0 = tile_q0[bx];
   const int row0 = cu_q[seq];
   const int q_len = cu_q[seq + 1] - row0;

@@ -347,7 +347,8 @@ def test_speech_replica_sleeps_and_wakes_with_its_graphs_on_gpu():
         eng.wake_up()
         assert eng.transcribe(wave) == first
         sampled = eng.transcribe(wave, temperature=0.8)
-        assert len(sampled) == 1 and len(sampled[0]) == 36
+        # a sampled answer may draw the end-of-text token before the length limit
+        assert len(sampled) == 1 and 1 <= len(sampled[0]) <= 36
     finally:
         eng.shutdown()
 
@@ -490,3 +491,74 @@ def test_packed_decode_weights_option_serves_the_same_model():
     eng.wake_up()
     assert len(list(m.packed_tensors())) == 2 * len(m.layers) and len(list(m.weight_tensors())) == n_weights
     assert eng.generate(ps, copy.deepcopy(sp)) == got
+
+
+@pytest.mark.parametrize("model", ["tiny-llama-gqa", "tiny-mixtral"])
+def test_small_prefill_parts_replay_graphs_and_mixed_steps_take_two(model):
+    """New turns arriving while other sequences decode: the decode rows replay their graph and the
+    prefill part (a short question behind a cached history, several at once, a chunk tail) replays
+    a prefill graph of its row bucket.  The steps must really have taken the graphs, and every
+    step's logits must be the eager engine's logits of that step.  (Tokens are compared through the
+    logits: the eager engine computes a mixed step's decode rows inside one large product and the
+    graphs compute them in the decode-sized one, so bf16 rounding differs and a tiny random model's
+    near-ties may flip; from the first flipped token on the two runs are different sequences.)"""
+    def drive(eng):
+        seen = _capture_logits(eng)
+        per_step = []
+
+        def step():
+            n0 = len(seen)
+            eng.step()
+            per_step.append(torch.cat(seen[n0:]) if len(seen) > n0 else None)
+
+        sp = lambda n: SamplingParams(max_tokens=n, temperature=0, ignore_eos=True)  # noqa: E731
+        base = prompts(3, 200, seed=3)
+        reqs = [eng.add_request(p, sp(40)) for p in base]
+        for _ in range(6):
+            step()
+        # a second wave joins running decodes: two short prompts, one that shares a cached prefix
+        late = [prompts(1, 30, seed=4)[0], prompts(1, 90, seed=5)[0], base[0][:128] + prompts(1, 17, seed=6)[0]]
+        reqs += [eng.add_request(p, sp(12)) for p in late]
+        for _ in range(4):
+            step()
+        reqs.append(eng.add_request(prompts(1, 300, seed=7)[0], sp(5)))  # 300 rows: the 512 bucket
+        while eng.has_work():
+            step()
+        return [r.output_ids for r in reqs], per_step
+
+    graphs = gpu_engine(model, budget=512)
+    got, got_logits = drive(graphs)
+    kinds = dict(graphs.runner.step_kinds)
+    eager = gpu_engine(model, budget=512, enforce_eager=True)
+    want, want_logits = drive(eager)
+    assert kinds["mixed_graphs"] >= 2 and kinds["prefill_graph"] >= 1 and kinds["decode_graph"] > 10, kinds
+    assert kinds["eager"] == 0, kinds
+    assert sorted(graphs.runner._prefill_graphs) and set(graphs.runner._prefill_graphs) <= {64, 128, 256, 512}
+    compared = 0
+    for step, (a, b) in enumerate(zip(got_logits, want_logits)):
+        assert (a is None) == (b is None) and (a is None or a.shape == b.shape), f"step {step}"
+        if a is None:
+            continue
+        cos = torch.nn.functional.cosine_similarity(a, b, dim=1)
+        assert cos.min().item() > 0.999, f"step {step}: logits cosine {cos.tolist()}"
+        compared += 1
+        if a.argmax(1).tolist() != b.argmax(1).tolist():
+            break  # a near-tie flipped: from here on the two engines hold different sequences
+    # the comparison must have covered the steps this test is about: the mixed steps of the second
+    # wave (steps 6..9) and the 300-row prefill that joins at step 10
+    assert compared >= 11, (compared, got, want)
+
+
+def test_prefill_graph_handles_eight_sequences_and_falls_back_beyond():
+    eng = gpu_engine("tiny-llama-gqa", budget=2048, seqs=32)
+    sp = SamplingParams(max_tokens=4, temperature=0, ignore_eos=True)
+    few = [eng.add_request(p, copy.deepcopy(sp)) for p in prompts(8, 40, seed=8)]
+    while eng.has_work():
+        eng.step()
+    assert eng.runner.step_kinds["prefill_graph"] == 1 and eng.runner.step_kinds["eager"] == 0
+    many = [eng.add_request(p, copy.deepcopy(sp)) for p in prompts(9, 40, seed=8)]  # nine sequences: eager
+    while eng.has_work():
+        eng.step()
+    assert eng.runner.step_kinds["eager"] == 1
+    # the same prompts give the same answers on either path
+    assert [r.output_ids for r in few] == [r.output_ids for r in many[:8]]

@@ -200,6 +200,8 @@ class LLMEngine:
         pr["t_plan"] = self.runner.t_plan
         pr["t_materialize"] = self.runner.t_materialize
         pr["t_launch"] = self.runner.t_launch
+        for kind, n in self.runner.step_kinds.items():  # how steps ran: captured graphs or eager launches
+            pr["steps_" + kind] = n
         return outputs
 
     def _stop_reason(self, req: Request, tok: int) -> str | None:

@@ -37,6 +37,11 @@ from .scheduler import ScheduledSeq, SchedulerOutput
 log = logging.getLogger("vpsa.runner")
 
 _GRAPH_BUCKETS = [1, 2, 4, 8, 12, 16, 24, 32, 40, 48, 64, 80, 96, 128, 160, 192, 256]
+# Prefill parts small enough to be worth a graph: the new turn of a conversation whose history is
+# cached, the tail of a chunked prompt.  A graph holds this many rows (padded) in up to this many
+# sequences; larger prefills run eagerly (their GPU time dwarfs the launches).
+_PREFILL_ROW_BUCKETS = [64, 128, 256, 512]
+_PREFILL_GRAPH_SEQS = 8
 
 
 class ModelRunner:
@@ -77,6 +82,9 @@ class ModelRunner:
                            and self.kv_head_dim == ops.HEAD_DIM_HIP
                            and (not self.distributed or self._tp_graphs_ready()))
         self._graphs: dict[int, dict] = {}
+        self._prefill_graphs: dict[int, dict] = {}
+        # steps by how they ran (decode graph, prefill graph, both, eager)
+        self.step_kinds = {"decode_graph": 0, "prefill_graph": 0, "mixed_graphs": 0, "eager": 0}
         self._row_track: dict[tuple, dict] = {}  # driver: what each graph row's block table holds
         self._graph_pool = None
         self._pin = device.type == "cuda"
@@ -341,10 +349,15 @@ class ModelRunner:
                 s.req.load_event = None
         if self.device.type == "cuda":
             ops.ensure_device()  # the calling thread may never have selected this process's GPU
-        if (self.use_graphs and not out.prefills
-                and all(s.samples for s in out.decodes)
-                and len(out.decodes) <= _GRAPH_BUCKETS[-1]):
-            return self._execute_decode_graph(out.decodes)
+        if self.use_graphs:
+            dec_ok = (all(s.samples for s in out.decodes) and len(out.decodes) <= _GRAPH_BUCKETS[-1])
+            if not out.prefills and dec_ok:
+                self.step_kinds["decode_graph"] += 1
+                return self._execute_decode_graph(out.decodes)
+            if dec_ok and self._prefill_graph_ok(out.prefills):
+                self.step_kinds["mixed_graphs" if out.decodes else "prefill_graph"] += 1
+                return self._execute_graph_pair(out.decodes, out.prefills)
+        self.step_kinds["eager"] += 1
         t0 = time.perf_counter()
         plan, sample_seqs = self._plan(out.decodes, out.prefills)
         self.t_plan += time.perf_counter() - t0
@@ -412,6 +425,7 @@ class ModelRunner:
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         self._graphs.clear()
+        self._prefill_graphs.clear()
         self._row_track.clear()
         self._graph_pool = None
         self._sleep_stash = []
@@ -496,9 +510,9 @@ class ModelRunner:
         st.update(graph=g, logits=logits, toks=toks, meta=meta, ws_o=ws_o, ws_ml=ws_ml)
         return st
 
-    def _execute_decode_graph(self, decodes: list[ScheduledSeq]):
+    def _launch_decode_graph(self, decodes: list[ScheduledSeq]) -> dict:
         """Driver: describe the step as a compact plan (per-row scalars and the block-table rows
-        that changed), send it to the replica's other ranks, replay the graph, sample."""
+        that changed), send it to the replica's other ranks, replay the graph."""
         n = len(decodes)
         bsz = self._bucket(n)
         lora = self.model.lora
@@ -537,12 +551,159 @@ class ModelRunner:
         if self.distributed:
             if not replica_broadcast_ints(self._decode_plan_to_ints(plan)):
                 replica_broadcast(("dstep", plan))
-        st = self._replay_decode(plan)
+        return self._replay_decode(plan)
+
+    def _execute_decode_graph(self, decodes: list[ScheduledSeq]):
+        st = self._launch_decode_graph(decodes)
         reqs = [s.req for s in decodes]
         toks, infos = self.sampler.sample(st["logits"], reqs, st["toks"])
         if self.distributed:
             check_collectives()
         return list(zip(decodes, toks, infos))
+
+    # ------------------------------------------------------------------ HIP-graph prefill parts
+    def _prefill_graph_ok(self, prefills: list[ScheduledSeq]) -> bool:
+        """A prefill part that a captured graph can hold: one rank, no adapters, no pooling, at most
+        ``_PREFILL_GRAPH_SEQS`` sequences and the largest row bucket."""
+        if (not prefills or self.distributed or len(prefills) > _PREFILL_GRAPH_SEQS
+                or sum(s.n for s in prefills) > _PREFILL_ROW_BUCKETS[-1]):
+            return False
+        lora = self.model.lora is not None
+        return not any(s.req.pooling or (lora and s.req.lora_slot >= 0) for s in prefills)
+
+    def _capture_prefill(self, rows: int) -> dict:
+        """Graph of a prefill-only forward pass over ``rows`` rows in up to ``_PREFILL_GRAPH_SEQS``
+        sequences.  Everything the kernels read that changes from step to step lives in two device
+        arrays (one per integer width) with pinned host twins, sent with one copy each, and the
+        block tables.  Unused rows carry slot -1 (nothing is cached), unused sequences are empty,
+        unused work-list entries are -1 (their workgroups leave at once)."""
+        dev = self.device
+        S = _PREFILL_GRAPH_SEQS
+        mp = self.max_pages_per_seq
+        tile = ops.prefill_tile_rows([rows], self.model.n_q, self.model.n_kv)
+        n_tiles = rows // tile + S  # every sequence may end in a partial tile
+        # int32: pos[rows] | cu_q[S + 1] | ctx[S] | tile_seq[n_tiles] | tile_q0[n_tiles], each part
+        # starting on a 16-byte boundary
+        def up4(n):
+            return (n + 3) // 4 * 4
+        o_pos, o_cu = 0, up4(rows)
+        o_ctx = o_cu + up4(S + 1)
+        o_ts = o_ctx + up4(S)
+        o_tq = o_ts + up4(n_tiles)
+        n32 = o_tq + up4(n_tiles)
+        # int64: ids[rows] | slots[rows] | logits_rows[S]
+        n64 = 2 * rows + S
+        d32 = torch.zeros(n32, dtype=torch.int32, device=dev)
+        d64 = torch.zeros(n64, dtype=torch.int64, device=dev)
+        h32 = torch.zeros(n32, dtype=torch.int32)
+        h64 = torch.zeros(n64, dtype=torch.int64)
+        hbt = torch.zeros((S, mp), dtype=torch.int32)
+        if self._pin:
+            h32, h64, hbt = h32.pin_memory(), h64.pin_memory(), hbt.pin_memory()
+        h32[o_ts:o_ts + n_tiles] = -1
+        h64[rows:2 * rows] = -1
+        d32.copy_(h32)
+        d64.copy_(h64)
+        bt = torch.zeros((S, mp), dtype=torch.int32, device=dev)
+        st = {"rows": rows, "tile": tile, "n_tiles": n_tiles, "d32": d32, "d64": d64, "h32": h32, "h64": h64,
+              "hbt": hbt, "bt": bt, "n32": h32.numpy(), "n64": h64.numpy(), "nbt": hbt.numpy(),
+              "off": (o_pos, o_cu, o_ctx, o_ts, o_tq), "copied": torch.cuda.Event()}
+        ids = d64[:rows]
+        meta = BatchMeta(positions=d32[o_pos:o_pos + rows], slots=d64[rows:2 * rows], num_decode=0,
+                         num_prefill_seqs=S, pre_block_tables=bt, pre_cu_q=d32[o_cu:o_cu + S + 1],
+                         pre_ctx_lens=d32[o_ctx:o_ctx + S], pre_tile_seq=d32[o_ts:o_ts + n_tiles],
+                         pre_tile_q0=d32[o_tq:o_tq + n_tiles], pre_tile_rows=tile,
+                         logits_rows=d64[2 * rows:2 * rows + S], pre_padded=True)
+
+        def run():
+            hidden = self.model.forward(ids, self.pool, meta)
+            logits = self.model.compute_logits(hidden)
+            return logits, ops.argmax(logits)
+
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            run()
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self._graph_pool):
+            logits, toks = run()
+        if self._graph_pool is None:
+            self._graph_pool = g.pool()
+        st.update(graph=g, logits=logits, toks=toks, meta=meta)
+        return st
+
+    def _launch_prefill_graph(self, prefills: list[ScheduledSeq]):
+        """Fill the graph inputs of the smallest row bucket that holds these sequences and replay;
+        returns (state, sampling sequences in logits-row order)."""
+        total = sum(s.n for s in prefills)
+        rows = next(b for b in _PREFILL_ROW_BUCKETS if b >= total)
+        st = self._prefill_graphs.get(rows)
+        if st is None:
+            t0 = time.time()
+            st = self._prefill_graphs[rows] = self._capture_prefill(rows)
+            log.info("captured prefill graph for %d rows in %.2fs", rows, time.time() - t0)
+        S = _PREFILL_GRAPH_SEQS
+        o_pos, o_cu, o_ctx, o_ts, o_tq = st["off"]
+        n32, n64, nbt = st["n32"], st["n64"], st["nbt"]
+        st["copied"].synchronize()  # the previous replay's copies have left the pinned twins
+        n64[rows:2 * rows] = -1
+        n64[2 * rows:] = 0
+        n32[o_cu:o_cu + S + 1] = 0
+        n32[o_ctx:o_ctx + S] = 0
+        n32[o_ts:o_ts + st["n_tiles"]] = -1
+        row = 0
+        sample_seqs: list[ScheduledSeq] = []
+        q_lens, ctx = [], []
+        for i, s in enumerate(prefills):
+            r = s.req
+            a, n = s.start, s.n
+            n64[row:row + n] = r.prompt_ids[a:a + n] if a + n <= r.prompt_len else r.all_ids[a:a + n]
+            t = np.arange(a, a + n, dtype=np.int64)
+            n32[o_pos + row:o_pos + row + n] = t
+            first = a // PAGE
+            pg = np.asarray(r.pages[first:(a + n - 1) // PAGE + 1], dtype=np.int64)
+            n64[rows + row:rows + row + n] = pg[t // PAGE - first] * PAGE + t % PAGE
+            k = len(r.pages)
+            nbt[i, :k] = r.pages
+            row += n
+            n32[o_cu + i + 1] = row
+            n32[o_ctx + i] = a + n
+            q_lens.append(n)
+            ctx.append(a + n)
+            if s.samples:
+                n64[2 * rows + len(sample_seqs)] = row - 1
+                sample_seqs.append(s)
+        n32[o_cu + len(prefills) + 1:o_cu + S + 1] = row  # the unused sequences are empty
+        ts, tq = ops.build_prefill_tiles(q_lens, self.model.n_q, self.model.n_kv, st["tile"], ctx)
+        n32[o_ts:o_ts + len(ts)] = ts
+        n32[o_tq:o_tq + len(tq)] = tq
+        st["d64"].copy_(st["h64"], non_blocking=True)
+        st["d32"].copy_(st["h32"], non_blocking=True)
+        st["bt"].copy_(st["hbt"], non_blocking=True)
+        st["copied"].record()
+        st["graph"].replay()
+        return st, sample_seqs
+
+    def _execute_graph_pair(self, decodes: list[ScheduledSeq], prefills: list[ScheduledSeq]):
+        """A step whose decode rows and (small) prefill part each replay a captured graph: two
+        launches instead of some four hundred, so the decode rows of a step that admits a new turn
+        do not wait for the host to issue the prefill's kernels one by one.  Both graphs are
+        launched before anything is read back."""
+        t0 = time.perf_counter()
+        dst = self._launch_decode_graph(decodes) if decodes else None
+        pst, pre_samples = self._launch_prefill_graph(prefills)
+        self.t_launch += time.perf_counter() - t0
+        out = []
+        if dst is not None:
+            toks, infos = self.sampler.sample(dst["logits"], [s.req for s in decodes], dst["toks"])
+            out += list(zip(decodes, toks, infos))
+        if pre_samples:
+            k = len(pre_samples)
+            toks, infos = self.sampler.sample(pst["logits"][:k], [s.req for s in pre_samples], pst["toks"][:k])
+            out += list(zip(pre_samples, toks, infos))
+        return out
 
     @staticmethod
     def _decode_plan_to_ints(plan: dict) -> list[int]:
@@ -607,7 +768,13 @@ class ModelRunner:
                 and b not in self._graphs]
         for b in sorted(todo, reverse=True):
             self._graphs[b] = self._capture(b)
-        return len(todo)
+        n = len(todo)
+        if not self.distributed:
+            for rows in reversed(_PREFILL_ROW_BUCKETS):  # the small prefill parts of mixed steps
+                if rows <= self.cfg.max_num_batched_tokens and rows not in self._prefill_graphs:
+                    self._prefill_graphs[rows] = self._capture_prefill(rows)
+                    n += 1
+        return n
 
     # ------------------------------------------------------------------ sleep / wake
     def sleep(self, level: int = 1) -> int:
@@ -622,6 +789,7 @@ class ModelRunner:
     def _sleep_local(self, level: int = 1) -> int:
         freed = 0
         self._graphs.clear()
+        self._prefill_graphs.clear()
         self._row_track.clear()
         self._graph_pool = None
         if self.device.type == "cuda":

@@ -31,6 +31,10 @@ class BatchMeta:
     pre_tile_seq: torch.Tensor | None = None
     pre_tile_q0: torch.Tensor | None = None
     pre_tile_rows: int | None = None  # tile height the work list was built for
+    # the batch is padded to a captured graph's fixed size: rows past the real ones belong to no
+    # sequence (slot -1, no tile covers them), so the attention output is zeroed first and what
+    # flows on from those rows stays finite
+    pre_padded: bool = False
     # rows whose logits are needed (last row of every sequence that samples this step)
     logits_rows: torch.Tensor | None = None  # int64 [num_out]
     # per-row LoRA slot (-1 = base model), only when adapters are active

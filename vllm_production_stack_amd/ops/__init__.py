@@ -211,7 +211,8 @@ def _attention_block(qkv, pool, layer, meta, n_q, n_kv, d, scale, cos_sin, rotar
     else:
         rope_and_cache(qkv, meta.positions, meta.slots, cos_sin, pool, layer, n_q, n_kv, d, rotary)
     t = qkv.shape[0]
-    out = torch.empty((t, n_q * d), dtype=qkv.dtype, device=qkv.device)
+    alloc = torch.zeros if getattr(meta, "pre_padded", False) else torch.empty
+    out = alloc((t, n_q * d), dtype=qkv.dtype, device=qkv.device)
     q = qkv[:, : n_q * d]
     if nd > 0:
         paged_decode(q[:nd], out[:nd], pool, layer, meta.dec_block_tables, meta.dec_ctx_lens, n_q, n_kv, d,
