@@ -372,8 +372,15 @@ async def run_phase(a, ctx, *, port0: int, routing: str, users_per_gpu: int, war
         if open_loop:
             # the reference's procedure against the same stack: requests arrive at a fixed rate,
             # sessions are pre-aged and new users keep joining (multi-round-qa.py's main loop)
+            prof1 = dict(engine.prof)
             if rank == 0:
                 open_loop_result = await loop.run_in_executor(None, run_open_loop_client, a, port0, n, open_loop)
+                if "error" not in open_loop_result:
+                    # what the engine did during this phase alone: how its steps ran (graphs or eager
+                    # launches) and how much host time went into issuing them
+                    open_loop_result["engine0_profile"] = {
+                        k: (round(v - prof1.get(k, 0), 3) if isinstance(v, float) else v - prof1.get(k, 0))
+                        for k, v in engine.prof.items()}
             await loop.run_in_executor(None, barrier)
         if rank != 0:
             return None

@@ -1027,7 +1027,7 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
   return d;
 }
 
-template <bool HEAD_MAJOR>
+template <bool HEAD_MAJOR, bool DIRECT>
 __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
     const uint16_t* __restrict__ q, long q_stride, uint16_t* __restrict__ out, long out_stride,
     const uint16_t* __restrict__ cache, long page_stride, long v_offset,
@@ -1145,6 +1145,35 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
       *reinterpret_cast<u32x4*>(buf + wk_off[i]) = sk[i];
       *reinterpret_cast<u32x4*>(buf + wv_off[i]) = sv[i];
     }
+  };
+  // DIRECT: the tile goes from global memory into its swizzled LDS image without passing through
+  // registers.  One load instruction of a wave fills one contiguous KiB of LDS, lane l the 16 bytes
+  // at l * 16: four keys' rows of the K image (16 slots each) or eight channels' rows of the V image
+  // (8 slots each).  The swizzle is therefore applied to the SOURCE: the lane reads the chunk whose
+  // place in the image its slot is.  Instruction i of wave w fills KiB 4 i + w of the 16.
+  int gk_off[4], gv_off[4];  // element offsets inside one head's K part / V part
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int kib = 4 * i + wave;
+    const int key = 4 * kib + (lane >> 4), c = (lane & 15) ^ (key & 15);
+    gk_off[i] = (c >> 2) * (PAGE * 32) + key * 32 + (c & 3) * 8;
+    const int d = 8 * kib + (lane >> 3), cv = (lane & 7) ^ ((d >> 1) & 7);
+    gv_off[i] = (cv >> 2) * (HEAD_DIM * 32) + d * 32 + (cv & 3) * 8;
+  }
+  auto direct_op = [&](const uint16_t* head_kp, char* buf, int i) {  // i = 0..7: K KiB, then V KiB
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    if (i < 4)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(head_kp + gk_off[i]), (lds_ptr_t)(buf + (4 * i + wave) * 1024),
+                                       16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(head_kp + v_offset + gv_off[i - 4]),
+                                       (lds_ptr_t)(buf + 16384 + (4 * (i - 4) + wave) * 1024), 16, 0, 0);
+  };
+  auto direct_tile = [&](int tile, char* buf) {
+    const uint16_t* head_kp = cache + (long)bt[tile] * page_stride + kv_head_off;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) direct_op(head_kp, buf, i);
   };
 
   f32x16 o_acc[2][4];
@@ -1316,7 +1345,9 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
         fr[n & 3] = v_frag(vbuf, vtt, 1, n - 16);
     };
     auto stage_op = [&](int i) {  // i = 0..7
-      if (STAGE == 1) {
+      if (DIRECT) {
+        direct_op(ld_kp, wbuf, i);
+      } else if (STAGE == 1) {
         if (i < 4)
           *reinterpret_cast<u32x4*>(wbuf + wk_off[i]) = sk[i];
         else
@@ -1336,8 +1367,14 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
       if (g + 1 < 32) exp_(g + 1);
       if (g + 2 < 24) fma_(g + 2);
       if (g >= 8 && g < 16) fma_(g + 16);
-      if (STAGE == 1 && g >= 16 && g < 24) stage_op(g - 16);
-      if (STAGE == 2 && g < 8) stage_op(g);
+      if (DIRECT) {
+        // the receiving buffer was last read in the first step of this tile (before the barrier):
+        // the loads leave at the start of the second step and have until the next tile's barrier
+        if (STAGE == 1 && g < 8) stage_op(g);
+      } else {
+        if (STAGE == 1 && g >= 16 && g < 24) stage_op(g - 16);
+        if (STAGE == 2 && g < 8) stage_op(g);
+      }
       fin_(g);  // last: its exponential was issued a whole gap ago, no wait state is needed
       if (!MASKED && g >= 25) {
         const int rb_ = g >= 28 ? 1 : 0, st_ = (g - 25) % 3;
@@ -1430,13 +1467,20 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
   // that receives tile t+2)
   int b_cur = 0, b_nxt = 32768, b_wr = 65536;
 
-  stage_load(0);
-  stage_write(lds);
-  // the first step multiplies an empty pending slice (pw1 = 0) by V^T of "tile -1": give that
-  // buffer finite contents
-  stage_write(lds + 65536);
-  stage_load(last < 1 ? last : 1);
-  stage_write(lds + 32768);
+  if (DIRECT) {
+    direct_tile(0, lds);
+    direct_tile(0, lds + 65536);  // (finite contents for the empty pending slice, see below)
+    direct_tile(last < 1 ? last : 1, lds + 32768);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    stage_load(0);
+    stage_write(lds);
+    // the first step multiplies an empty pending slice (pw1 = 0) by V^T of "tile -1": give that
+    // buffer finite contents
+    stage_write(lds + 65536);
+    stage_load(last < 1 ? last : 1);
+    stage_write(lds + 32768);
+  }
   __syncthreads();
 
   f32x16 sA[2], sB[2];
@@ -1456,6 +1500,7 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
     rescale(mA);                                                                                \
     step(std::integral_constant<int, 2>{}, std::integral_constant<bool, MASKED>{}, lds + b_wr, 1, \
          lds + b_cur, 1, lds + b_cur, 0, lds + b_wr, sA, sB, mB, (t));                          \
+    if (DIRECT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* tile t+1 has landed */      \
     __syncthreads();                                                                            \
     rescale(mB);                                                                                \
     step(std::integral_constant<int, 1>{}, std::integral_constant<bool, MASKED>{}, lds + b_cur, 0, \
@@ -1522,7 +1567,9 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
 // order when sequences have many q-tiles.  Fixed choices are for A/B timing and tests:
 // 0 = first generation, 1 = generation 2 without wave priorities, 2 = generation 2,
 // 3 = generation 2 head-major, 4 = generation 3, 5 = generation 3 head-major, 6 / 7 = as 4 / 5
-// without the instruction-interleave hints, 8 = generation 4, 9 = generation 4 head-major.
+// without the instruction-interleave hints, 8 = generation 4 with K/V tiles staged through
+// registers, 9 = the same head-major, 10 / 11 = generation 4 with K/V tiles loaded straight into
+// LDS (what the automatic choice takes).
 static int g_prefill_variant = -1;
 VPSA_EXPORT int vpsa_set_prefill_variant(int v) {
   const int old = g_prefill_variant;
@@ -1576,24 +1623,32 @@ VPSA_EXPORT int vpsa_paged_prefill_rope(const void* q, long q_stride, void* out,
     if (variant >= 0 && variant < 4) return -2;
     static bool attr_set = false;
     if (!attr_set) {
-      const void* fns[6] = {(const void*)paged_prefill_kernel_v3<false, 1>,
+      const void* fns[8] = {(const void*)paged_prefill_kernel_v3<false, 1>,
                             (const void*)paged_prefill_kernel_v3<true, 1>,
                             (const void*)paged_prefill_kernel_v3<false, 0>,
                             (const void*)paged_prefill_kernel_v3<true, 0>,
-                            (const void*)paged_prefill_kernel_v4<false>,
-                            (const void*)paged_prefill_kernel_v4<true>};
+                            (const void*)paged_prefill_kernel_v4<false, false>,
+                            (const void*)paged_prefill_kernel_v4<true, false>,
+                            (const void*)paged_prefill_kernel_v4<false, true>,
+                            (const void*)paged_prefill_kernel_v4<true, true>};
       for (const void* f : fns)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 98304) != hipSuccess)
           return -3;
       attr_set = true;
     }
     dim3 grid(num_tiles, n_kv * (G / 4)), block(256);
-    if (variant < 0) variant = many_tiles ? 9 : 8;
-    if (variant == 9) {
-      hipLaunchKernelGGL((paged_prefill_kernel_v4<true>), grid, block, 98304, stream,
+    if (variant < 0) variant = many_tiles ? 11 : 10;
+    if (variant == 11) {
+      hipLaunchKernelGGL((paged_prefill_kernel_v4<true, true>), grid, block, 98304, stream,
+                         VPSA_PREFILL_ARGS, rope);
+    } else if (variant == 10) {
+      hipLaunchKernelGGL((paged_prefill_kernel_v4<false, true>), grid, block, 98304, stream,
+                         VPSA_PREFILL_ARGS, rope);
+    } else if (variant == 9) {
+      hipLaunchKernelGGL((paged_prefill_kernel_v4<true, false>), grid, block, 98304, stream,
                          VPSA_PREFILL_ARGS, rope);
     } else if (variant == 8) {
-      hipLaunchKernelGGL((paged_prefill_kernel_v4<false>), grid, block, 98304, stream,
+      hipLaunchKernelGGL((paged_prefill_kernel_v4<false, false>), grid, block, 98304, stream,
                          VPSA_PREFILL_ARGS, rope);
     } else if (variant == 5) {
       hipLaunchKernelGGL((paged_prefill_kernel_v3<true, 1>), grid, block, 98304, stream,

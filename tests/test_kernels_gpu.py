@@ -140,7 +140,7 @@ def _run_prefill(q, pool, layer, bt, q_lens, ctx, n_q, n_kv, variant, hd=128):
     return out, cu, ctx_t, rows
 
 
-@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("n_q,n_kv", [(32, 8), (8, 8), (8, 4), (16, 2), (28, 4), (10, 2), (12, 2)])
 def test_paged_prefill_matches_reference(n_q, n_kv, variant):
     if not _prefill_variant_ok(variant, n_q, n_kv):
@@ -164,7 +164,47 @@ def test_paged_prefill_matches_reference(n_q, n_kv, variant):
     assert err < REL_TOL, err
 
 
-@pytest.mark.parametrize("variant", [-1, 8, 9])
+@pytest.mark.parametrize("variant", [-1, 0, 2, 4, 8, 10])
+def test_paged_prefill_skips_padding_of_a_fixed_size_work_list(variant):
+    """A captured graph launches the kernel with a work list, a sequence table and a row count of
+    fixed size: entries past the real ones are -1 (their workgroups leave at once), sequences past
+    the real ones are empty, rows past the real ones belong to nobody and must stay untouched."""
+    n_q, n_kv, hd = 32, 8, 128
+    if not _prefill_variant_ok(variant, n_q, n_kv):
+        pytest.skip("the 64-row kernel takes GQA ratios that are multiples of 4")
+    torch.manual_seed(40)
+    cases = [(70, 300), (5, 64), (33, 0)]
+    q_lens = [c[0] for c in cases]
+    ctx = [c[0] + c[1] for c in cases]
+    S, rows_total = 8, 256
+    max_pages = 16
+    pool = _v_offset_pool(len(cases) * max_pages + 3, 1, n_kv, seed=41)
+    bt = torch.zeros((S, max_pages), dtype=torch.int32, device=DEV)
+    bt[:len(cases)] = _block_tables(len(cases), max_pages, pool.shape[0], 42)
+    q = torch.randn(rows_total, n_q * hd, device=DEV).to(BF)
+    real = sum(q_lens)
+    cu = torch.tensor([0, 70, 75, 108] + [108] * (S - 3), dtype=torch.int32, device=DEV)
+    ctx_t = torch.tensor(ctx + [0] * (S - 3), dtype=torch.int32, device=DEV)
+    out = torch.full_like(q, 7.0)
+    prev = ops.set_prefill_variant(variant)
+    try:
+        rows = ops.prefill_tile_rows(q_lens, n_q, n_kv)
+        ts, tq = ops.build_prefill_tiles(q_lens, n_q, n_kv, rows, ctx)
+        pad = rows_total // rows + S - len(ts)
+        # padding in the middle as well as at the end: position in the list must not matter
+        ts = torch.tensor(ts[:1] + [-1] * 2 + ts[1:] + [-1] * (pad - 2), dtype=torch.int32, device=DEV)
+        tq = torch.tensor(tq[:1] + [0] * 2 + tq[1:] + [0] * (pad - 2), dtype=torch.int32, device=DEV)
+        ops.paged_prefill(q, out, pool, 0, bt, cu, ctx_t, ts, tq, n_q, n_kv, hd, 1.0 / math.sqrt(hd), rows)
+    finally:
+        ops.set_prefill_variant(prev)
+    torch.cuda.synchronize()
+    out_ref = torch.zeros_like(q[:real])
+    ref.paged_prefill(q[:real], out_ref, pool, 0, bt[:3], cu[:4], ctx_t[:3], n_q, n_kv, hd, 1.0 / math.sqrt(hd))
+    assert _rel_row_err(out[:real], out_ref, n_q) < REL_TOL
+    assert (out[real:] == 7.0).all(), "rows that belong to no sequence were written"
+
+
+@pytest.mark.parametrize("variant", [-1, 8, 9, 10, 11])
 @pytest.mark.parametrize("n_q,n_kv", [(32, 8), (8, 2)])
 def test_paged_prefill_rotates_queries_itself(n_q, n_kv, variant):
     """Prefill rows: K / V go to the cache through the tile kernel (``kv_cache_write``: rotated K,
@@ -229,7 +269,7 @@ def test_paged_prefill_rotates_queries_itself(n_q, n_kv, variant):
     assert err < 8e-3, err  # the two rotations may round a query element to neighbouring bf16 values
 
 
-@pytest.mark.parametrize("variant", [2, 4, 8])
+@pytest.mark.parametrize("variant", [2, 4, 8, 10])
 def test_paged_prefill_forced_rescale(variant):
     """A key far larger than the rest late in the context forces the online-softmax
     rescale branch on a chosen tile (in the second half of the tile for the 64-row kernel)."""
@@ -270,7 +310,7 @@ def _ref_prefill_long(q, pool, layer, bt_row, ql, ctx, n_q, n_kv, hd):
     return out
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 8, 9])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 8, 9, 10, 11])
 @pytest.mark.parametrize("ql,prefix", [(4616, 16384), (1024, 15360)])
 def test_paged_prefill_long_context(ql, prefix, variant):
     """The last chunk of a 21k-token prompt (4616 rows behind 16384 cached keys, 329 pages deep in

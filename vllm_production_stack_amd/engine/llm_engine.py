@@ -200,6 +200,7 @@ class LLMEngine:
         pr["t_plan"] = self.runner.t_plan
         pr["t_materialize"] = self.runner.t_materialize
         pr["t_launch"] = self.runner.t_launch
+        pr["t_launch_graph_pairs"] = self.runner.t_launch_graph_pairs
         for kind, n in self.runner.step_kinds.items():  # how steps ran: captured graphs or eager launches
             pr["steps_" + kind] = n
         return outputs

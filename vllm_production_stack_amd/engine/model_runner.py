@@ -92,6 +92,7 @@ class ModelRunner:
         self._sleep_stash: list[tuple[torch.Tensor, torch.Tensor]] = []
         # host-side seconds of eager steps: plan lists, device tensors, kernel launches
         self.t_plan = self.t_materialize = self.t_launch = 0.0
+        self.t_launch_graph_pairs = 0.0  # of t_launch: steps whose prefill part replayed a graph
 
     def _pack_decode_weights(self) -> None:
         mode = getattr(self.cfg, "packed_decode_weights", "off")
@@ -694,7 +695,9 @@ class ModelRunner:
         t0 = time.perf_counter()
         dst = self._launch_decode_graph(decodes) if decodes else None
         pst, pre_samples = self._launch_prefill_graph(prefills)
-        self.t_launch += time.perf_counter() - t0
+        dt = time.perf_counter() - t0
+        self.t_launch += dt
+        self.t_launch_graph_pairs += dt
         out = []
         if dst is not None:
             toks, infos = self.sampler.sample(dst["logits"], [s.req for s in decodes], dst["toks"])
