@@ -1027,7 +1027,10 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
   return d;
 }
 
-template <bool HEAD_MAJOR, bool DIRECT>
+// DBG: timing experiments with WRONG results (bit 0: no barrier inside the tile loop, bit 1: no
+// K/V loads inside the tile loop, bit 2: a plain move in place of every exponential); 0 in
+// every production launch.
+template <bool HEAD_MAJOR, bool DIRECT, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
     const uint16_t* __restrict__ q, long q_stride, uint16_t* __restrict__ out, long out_stride,
     const uint16_t* __restrict__ cache, long page_stride, long v_offset,
@@ -1318,7 +1321,10 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
       VPSA_PIN(pv[v]);
     };
     auto exp_ = [&](int v) {
-      pv[v] = __builtin_amdgcn_exp2f(pv[v]);
+      if (DBG & 4)
+        asm volatile("v_mov_b32 %0, %0" : "+v"(pv[v]));
+      else
+        pv[v] = __builtin_amdgcn_exp2f(pv[v]);
       VPSA_PIN(pv[v]);
     };
     auto fin_ = [&](int v) {
@@ -1346,7 +1352,7 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
     };
     auto stage_op = [&](int i) {  // i = 0..7
       if (DIRECT) {
-        direct_op(ld_kp, wbuf, i);
+        if (!(DBG & 2)) direct_op(ld_kp, wbuf, i);
       } else if (STAGE == 1) {
         if (i < 4)
           *reinterpret_cast<u32x4*>(wbuf + wk_off[i]) = sk[i];
@@ -1501,7 +1507,7 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
     step(std::integral_constant<int, 2>{}, std::integral_constant<bool, MASKED>{}, lds + b_wr, 1, \
          lds + b_cur, 1, lds + b_cur, 0, lds + b_wr, sA, sB, mB, (t));                          \
     if (DIRECT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* tile t+1 has landed */      \
-    __syncthreads();                                                                            \
+    if (!(DBG & 1)) __syncthreads();                                                            \
     rescale(mB);                                                                                \
     step(std::integral_constant<int, 1>{}, std::integral_constant<bool, MASKED>{}, lds + b_cur, 0, \
          lds + b_nxt, 0, lds + b_cur, 1, lds + b_wr, sB, sA, mA, (t) + 1);                      \
@@ -1569,7 +1575,8 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
 // 3 = generation 2 head-major, 4 = generation 3, 5 = generation 3 head-major, 6 / 7 = as 4 / 5
 // without the instruction-interleave hints, 8 = generation 4 with K/V tiles staged through
 // registers, 9 = the same head-major, 10 / 11 = generation 4 with K/V tiles loaded straight into
-// LDS (what the automatic choice takes).
+// LDS (what the automatic choice takes); 12 / 13 / 14 = timing experiments on 11 with wrong results
+// (no barrier / no loads / no exponentials inside the tile loop).
 static int g_prefill_variant = -1;
 VPSA_EXPORT int vpsa_set_prefill_variant(int v) {
   const int old = g_prefill_variant;
@@ -1623,14 +1630,17 @@ VPSA_EXPORT int vpsa_paged_prefill_rope(const void* q, long q_stride, void* out,
     if (variant >= 0 && variant < 4) return -2;
     static bool attr_set = false;
     if (!attr_set) {
-      const void* fns[8] = {(const void*)paged_prefill_kernel_v3<false, 1>,
-                            (const void*)paged_prefill_kernel_v3<true, 1>,
-                            (const void*)paged_prefill_kernel_v3<false, 0>,
-                            (const void*)paged_prefill_kernel_v3<true, 0>,
-                            (const void*)paged_prefill_kernel_v4<false, false>,
-                            (const void*)paged_prefill_kernel_v4<true, false>,
-                            (const void*)paged_prefill_kernel_v4<false, true>,
-                            (const void*)paged_prefill_kernel_v4<true, true>};
+      const void* fns[11] = {(const void*)paged_prefill_kernel_v4<true, true, 1>,
+                             (const void*)paged_prefill_kernel_v4<true, true, 2>,
+                             (const void*)paged_prefill_kernel_v4<true, true, 4>,
+                             (const void*)paged_prefill_kernel_v3<false, 1>,
+                             (const void*)paged_prefill_kernel_v3<true, 1>,
+                             (const void*)paged_prefill_kernel_v3<false, 0>,
+                             (const void*)paged_prefill_kernel_v3<true, 0>,
+                             (const void*)paged_prefill_kernel_v4<false, false>,
+                             (const void*)paged_prefill_kernel_v4<true, false>,
+                             (const void*)paged_prefill_kernel_v4<false, true>,
+                             (const void*)paged_prefill_kernel_v4<true, true>};
       for (const void* f : fns)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 98304) != hipSuccess)
           return -3;
@@ -1638,7 +1648,14 @@ VPSA_EXPORT int vpsa_paged_prefill_rope(const void* q, long q_stride, void* out,
     }
     dim3 grid(num_tiles, n_kv * (G / 4)), block(256);
     if (variant < 0) variant = many_tiles ? 11 : 10;
-    if (variant == 11) {
+    if (variant >= 12 && variant <= 14) {
+      if (variant == 12)
+        hipLaunchKernelGGL((paged_prefill_kernel_v4<true, true, 1>), grid, block, 98304, stream, VPSA_PREFILL_ARGS, rope);
+      else if (variant == 13)
+        hipLaunchKernelGGL((paged_prefill_kernel_v4<true, true, 2>), grid, block, 98304, stream, VPSA_PREFILL_ARGS, rope);
+      else
+        hipLaunchKernelGGL((paged_prefill_kernel_v4<true, true, 4>), grid, block, 98304, stream, VPSA_PREFILL_ARGS, rope);
+    } else if (variant == 11) {
       hipLaunchKernelGGL((paged_prefill_kernel_v4<true, true>), grid, block, 98304, stream,
                          VPSA_PREFILL_ARGS, rope);
     } else if (variant == 10) {

@@ -24,7 +24,7 @@ def test_routercore_selftest_under_sanitizer(tmp_path, name, flags):
         pytest.skip("no g++")
     exe = tmp_path / f"selftest-{name}"
     build = subprocess.run([gxx, "-std=c++17", "-O1", "-g", *flags, "-I", str(ROOT / "csrc"), *SRC,
-                            "-o", str(exe), *libs, "-lpthread"], capture_output=True, text=True)
+                            "-o", str(exe), "-lpthread"], capture_output=True, text=True)
     if build.returncode != 0 and "cannot find" in build.stderr:
         pytest.skip(f"sanitizer runtime not installed: {build.stderr.splitlines()[-1]}")
     assert build.returncode == 0, build.stderr
