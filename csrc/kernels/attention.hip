@@ -1506,7 +1506,9 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
     rescale(mA);                                                                                \
     step(std::integral_constant<int, 2>{}, std::integral_constant<bool, MASKED>{}, lds + b_wr, 1, \
          lds + b_cur, 1, lds + b_cur, 0, lds + b_wr, sA, sB, mB, (t));                          \
-    if (DIRECT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* tile t+1 has landed */      \
+    /* tile t+1 has landed (a ring of four with two tiles of slack measured the same: the     \
+       loads cost throughput, not latency) */                                                   \
+    if (DIRECT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
     if (!(DBG & 1)) __syncthreads();                                                            \
     rescale(mB);                                                                                \
     step(std::integral_constant<int, 1>{}, std::integral_constant<bool, MASKED>{}, lds + b_cur, 0, \
@@ -1528,6 +1530,9 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
 #undef VPSA_V4_TILE
   // last tile (compiler-scheduled): the slice left pending by the steps, then both halves
   {
+    // (the tail of the loop re-requests the last tile into free buffers: nothing may still be
+    // on its way into LDS when this workgroup ends)
+    if (DIRECT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     mfma_drain();
     if (last > 0) pv_slice(lds + b_wr, 1, 1, pw1);
     u32x4 pk[2];

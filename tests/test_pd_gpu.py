@@ -1,7 +1,8 @@
 """Disaggregated prefill across real processes on the GPU: one prefill and two decode replicas of a
-tiny model behind the router (benchmarks/pd_pools.py), pages pushed through hipIpc into a landing
-window with fewer slots than a prompt has pages, so every push goes in rounds and the two
-concurrent producers' requests contend for the slots."""
+tiny model behind the router (benchmarks/pd_pools.py).  By default the decode replicas export their
+KV pools and pages are written where they will live (``ipc-direct``); with the export switched off
+they go through hipIpc into a landing window with fewer slots than a prompt has pages, so every
+push goes in rounds and the two concurrent producers' requests contend for the slots."""
 
 import json
 import os
@@ -14,8 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_pd_pools_push_by_hipipc_between_processes():
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VPSA_PD_LANDING_MIB="1")
+@pytest.mark.parametrize("export_pool,mode", [("1", "ipc-direct"), ("0", "ipc")])
+def test_pd_pools_push_by_hipipc_between_processes(export_pool, mode):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VPSA_PD_LANDING_MIB="1", VPSA_PD_EXPORT_POOL=export_pool)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "benchmarks", "pd_pools.py"), "--model", "tiny-llama-gqa",
                         "--prefill", "1", "--decode", "2", "--requests", "4", "--concurrency", "2",
                         "--prompt-tokens", "700", "--pages", "96", "--base-port", "19920", "--request-timeout", "60"],
@@ -24,5 +26,5 @@ def test_pd_pools_push_by_hipipc_between_processes():
     res = json.loads(p.stdout.strip().splitlines()[-1])
     assert res["pass"] and res["requests_routed_prefill_then_decode"] == 4
     push = res["push_by_prefill_replica"]["prefill-0"]
-    assert push["by_mode"] == {"ipc": 4} and push["pages"] == 40
+    assert push["by_mode"] == {mode: 4} and push["pages"] == 40
     assert res["cached_tokens_min"] == 640 and res["first_answer_equals_self_computed"]
