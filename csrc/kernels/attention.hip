@@ -1030,6 +1030,8 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
 // DBG: timing experiments with WRONG results (bit 0: no barrier inside the tile loop, bit 1: no
 // K/V loads inside the tile loop, bit 2: a plain move in place of every exponential); 0 in
 // every production launch.
+#define SPLIT_REC_FLOATS (8192 + 256)
+
 template <bool HEAD_MAJOR, bool DIRECT, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
     const uint16_t* __restrict__ q, long q_stride, uint16_t* __restrict__ out, long out_stride,
@@ -1037,7 +1039,7 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
     const int* __restrict__ block_tables, int max_blocks, const int* __restrict__ cu_q,
     const int* __restrict__ ctx_lens, const int* __restrict__ tile_seq,
     const int* __restrict__ tile_q0, int n_q, int n_kv, float scale_log2e,
-    const float* __restrict__ rope) {
+    const float* __restrict__ rope, const int* __restrict__ tile_split, float* __restrict__ split_ws) {
   extern __shared__ __attribute__((aligned(16))) char lds[];  // 3 x (16 KiB K + 16 KiB V)
 
   const int tid = threadIdx.x;
@@ -1075,10 +1077,24 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
   }
   int b_last = q0 + 63;
   if (b_last > q_len - 1) b_last = q_len - 1;
-  const int n_tiles = (pos0 + b_last) / PAGE + 1;
-  const int last = n_tiles - 1;
+  const int n_tiles_all = (pos0 + b_last) / PAGE + 1;
   // tiles [0, n_full) lie entirely at or below the first row's position: no mask for any row
-  const int n_full = (pos0 + q0 + 1) / PAGE;
+  const int n_full_all = (pos0 + q0 + 1) / PAGE;
+  // Split work-list entries (few query tiles in front of a long context: one workgroup per tile
+  // and head group would walk hundreds of key tiles alone while the chip idles): the entry covers
+  // key tiles [kt0, kt1) only and leaves an unnormalised partial (O, row maxima, row sums) in
+  // split_ws record `part`; prefill_combine_kernel merges the records of a tile.  Everything below
+  // works on tile numbers and positions RELATIVE to kt0.  The host makes the last split at least
+  // three tiles long: a 64-row tile spans at most two key tiles of the diagonal, so every row sees
+  // at least one whole tile in every split it takes part in.
+  int kt0 = 0, kt1 = n_tiles_all, part = -1;
+  if (tile_split != nullptr) {
+    kt0 = tile_split[3 * bx];
+    kt1 = tile_split[3 * bx + 1] < n_tiles_all ? tile_split[3 * bx + 1] : n_tiles_all;
+    part = tile_split[3 * bx + 2];
+  }
+  const int last = kt1 - 1 - kt0;
+  const int n_full = n_full_all - kt0;
 
   bf16x8 qf[2][8];
 #pragma unroll
@@ -1120,8 +1136,10 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
     }
   }
 
-  const int* bt = block_tables + (long)seq * max_blocks;
+  const int* bt = block_tables + (long)seq * max_blocks + kt0;
   const long kv_head_off = (long)kvh * PAGE * HEAD_DIM;
+  my_pos[0] -= kt0 * PAGE;  // (the rotary table above took the absolute positions)
+  my_pos[1] -= kt0 * PAGE;
 
   u32x4 sk[4], sv[4];
   auto stage_load = [&](int tile) {
@@ -1554,6 +1572,22 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
   }
 
   mfma_drain();
+  if (part >= 0) {
+    // record = [2 row blocks][4 channel tiles][16 values][64 lanes] fp32, then [2][64] maxima and
+    // [2][64] sums: lane-major, so that the combine kernel (same lane roles) reads it back whole
+    float* rec = split_ws + ((long)(part * gridDim.y + by) * 4 + wave) * SPLIT_REC_FLOATS;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const float l_tot = l_run[rb] + __shfl_xor(l_run[rb], 32, 64);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rec[((rb * 4 + dt) * 16 + i) * 64 + lane] = o_acc[rb][dt][i];
+      rec[8192 + rb * 64 + lane] = m_run[rb];
+      rec[8192 + 128 + rb * 64 + lane] = l_tot;
+    }
+    return;
+  }
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
     const float l_tot = l_run[rb] + __shfl_xor(l_run[rb], 32, 64);
@@ -1569,6 +1603,53 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
           w[1] = pack_bf16x2(o_acc[rb][dt][4 * g4 + 2] * inv, o_acc[rb][dt][4 * g4 + 3] * inv);
           *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g4 + 4 * h) = w;
         }
+    }
+  }
+}
+
+// Merge the partial records of split work-list entries.  grid = (groups, head groups, 8): group g =
+// (sequence, first row of the tile, first record, number of records); blockIdx.z picks one (row
+// block, channel tile) slice of the record, a wave is a head and its lanes hold what they hold in
+// the attention kernel's epilogue: 16 values each, so the merge of a tile is spread over 8 x the
+// head groups workgroups and every record is read with whole-wave contiguous loads.
+__global__ __launch_bounds__(256) void prefill_combine_kernel(
+    const float* __restrict__ split_ws, const int* __restrict__ groups, uint16_t* __restrict__ out,
+    long out_stride, const int* __restrict__ cu_q, int n_q, int n_kv) {
+  const int nparts = groups[4 * blockIdx.x + 3];
+  if (nparts <= 0) return;  // padding
+  const int seq = groups[4 * blockIdx.x], q0 = groups[4 * blockIdx.x + 1], part0 = groups[4 * blockIdx.x + 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int by = blockIdx.y, rb = blockIdx.z >> 2, dt = blockIdx.z & 3;
+  const int G = n_q / n_kv, groups_per_kv = G >> 2;
+  const int head = (by / groups_per_kv) * G + (by % groups_per_kv) * 4 + wave;
+  const int row0 = cu_q[seq], q_len = cu_q[seq + 1] - row0;
+  const int row = q0 + 32 * rb + r;
+  const float* rec0 = split_ws + ((long)(part0 * gridDim.y + by) * 4 + wave) * SPLIT_REC_FLOATS;
+  const long rec_step = (long)gridDim.y * 4 * SPLIT_REC_FLOATS;
+  float m = NEG_BIG;
+  for (int p = 0; p < nparts; ++p) m = fmaxf(m, rec0[p * rec_step + 8192 + rb * 64 + lane]);
+  float l = 0.f;
+  float o[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) o[i] = 0.f;
+#pragma unroll 4
+  for (int p = 0; p < nparts; ++p) {
+    const float* rec = rec0 + p * rec_step;
+    const float f = __builtin_amdgcn_exp2f(rec[8192 + rb * 64 + lane] - m);
+    l += f * rec[8192 + 128 + rb * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] += f * rec[((rb * 4 + dt) * 16 + i) * 64 + lane];
+  }
+  if (row < q_len) {
+    const float inv = 1.f / l;
+    uint16_t* op = out + (long)(row0 + row) * out_stride + head * HEAD_DIM;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      u32x2 w;
+      w[0] = pack_bf16x2(o[4 * g4] * inv, o[4 * g4 + 1] * inv);
+      w[1] = pack_bf16x2(o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv);
+      *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * g4 + 4 * h) = w;
     }
   }
 }
@@ -1612,13 +1693,46 @@ VPSA_EXPORT int vpsa_prefill_fuses_rope(int n_q, int n_kv, int tile_rows) {
 // rope: null = q is already rotated; else the [position][HEAD_DIM] fp32 table (cos of the 64
 // channel pairs, then sin), and q holds UNROTATED rows at consecutive positions ending at each
 // sequence's context length.  Only the fourth-generation kernels take it (-4 otherwise).
+// tile_split: null, or [num_tiles][3] = (first key tile, end key tile, partial record or -1) per
+// work-list entry; entries with a record leave partials in split_ws (SPLIT_REC_FLOATS floats per
+// record, head group and head) and `groups` [num_groups][4] = (sequence, first row, first record,
+// number of records; 0 records = padding) says which records make up a tile: they are merged by a
+// second launch.  Fourth-generation kernels only (-4 otherwise).
+VPSA_EXPORT int vpsa_paged_prefill_split(const void* q, long q_stride, void* out, long out_stride,
+                                         const void* cache, long page_stride, long v_offset,
+                                         const int* block_tables, int max_blocks, const int* cu_q,
+                                         const int* ctx_lens, const int* tile_seq, const int* tile_q0,
+                                         int num_tiles, int num_seqs, int tile_rows, int n_q, int n_kv,
+                                         float scale, const float* rope, const int* tile_split,
+                                         float* split_ws, const int* groups, int num_groups,
+                                         hipStream_t stream);
+
+VPSA_EXPORT long vpsa_prefill_split_record_bytes(int n_q, int n_kv) {
+  // one record per (partial, head group of 4, head)
+  return (long)(n_q / 4) * 4 * SPLIT_REC_FLOATS * 4;
+}
+
 VPSA_EXPORT int vpsa_paged_prefill_rope(const void* q, long q_stride, void* out, long out_stride,
                                         const void* cache, long page_stride, long v_offset,
                                         const int* block_tables, int max_blocks, const int* cu_q,
                                         const int* ctx_lens, const int* tile_seq, const int* tile_q0,
                                         int num_tiles, int num_seqs, int tile_rows, int n_q, int n_kv,
                                         float scale, const float* rope, hipStream_t stream) {
+  return vpsa_paged_prefill_split(q, q_stride, out, out_stride, cache, page_stride, v_offset, block_tables,
+                                  max_blocks, cu_q, ctx_lens, tile_seq, tile_q0, num_tiles, num_seqs, tile_rows,
+                                  n_q, n_kv, scale, rope, nullptr, nullptr, nullptr, 0, stream);
+}
+
+VPSA_EXPORT int vpsa_paged_prefill_split(const void* q, long q_stride, void* out, long out_stride,
+                                         const void* cache, long page_stride, long v_offset,
+                                         const int* block_tables, int max_blocks, const int* cu_q,
+                                         const int* ctx_lens, const int* tile_seq, const int* tile_q0,
+                                         int num_tiles, int num_seqs, int tile_rows, int n_q, int n_kv,
+                                         float scale, const float* rope, const int* tile_split,
+                                         float* split_ws, const int* groups, int num_groups,
+                                         hipStream_t stream) {
   if (num_tiles <= 0) return 0;
+  if (tile_split != nullptr && (split_ws == nullptr || groups == nullptr)) return -1;
   if (rope != nullptr && !vpsa_prefill_fuses_rope(n_q, n_kv, tile_rows)) return -4;
   if (n_q % n_kv != 0) return -1;
   const int G = n_q / n_kv;
@@ -1653,25 +1767,26 @@ VPSA_EXPORT int vpsa_paged_prefill_rope(const void* q, long q_stride, void* out,
     }
     dim3 grid(num_tiles, n_kv * (G / 4)), block(256);
     if (variant < 0) variant = many_tiles ? 11 : 10;
+    if (tile_split != nullptr && variant < 8) return -4;
     if (variant >= 12 && variant <= 14) {
       if (variant == 12)
-        hipLaunchKernelGGL((paged_prefill_kernel_v4<true, true, 1>), grid, block, 98304, stream, VPSA_PREFILL_ARGS, rope);
+        hipLaunchKernelGGL((paged_prefill_kernel_v4<true, true, 1>), grid, block, 98304, stream, VPSA_PREFILL_ARGS, rope, tile_split, split_ws);
       else if (variant == 13)
-        hipLaunchKernelGGL((paged_prefill_kernel_v4<true, true, 2>), grid, block, 98304, stream, VPSA_PREFILL_ARGS, rope);
+        hipLaunchKernelGGL((paged_prefill_kernel_v4<true, true, 2>), grid, block, 98304, stream, VPSA_PREFILL_ARGS, rope, tile_split, split_ws);
       else
-        hipLaunchKernelGGL((paged_prefill_kernel_v4<true, true, 4>), grid, block, 98304, stream, VPSA_PREFILL_ARGS, rope);
+        hipLaunchKernelGGL((paged_prefill_kernel_v4<true, true, 4>), grid, block, 98304, stream, VPSA_PREFILL_ARGS, rope, tile_split, split_ws);
     } else if (variant == 11) {
       hipLaunchKernelGGL((paged_prefill_kernel_v4<true, true>), grid, block, 98304, stream,
-                         VPSA_PREFILL_ARGS, rope);
+                         VPSA_PREFILL_ARGS, rope, tile_split, split_ws);
     } else if (variant == 10) {
       hipLaunchKernelGGL((paged_prefill_kernel_v4<false, true>), grid, block, 98304, stream,
-                         VPSA_PREFILL_ARGS, rope);
+                         VPSA_PREFILL_ARGS, rope, tile_split, split_ws);
     } else if (variant == 9) {
       hipLaunchKernelGGL((paged_prefill_kernel_v4<true, false>), grid, block, 98304, stream,
-                         VPSA_PREFILL_ARGS, rope);
+                         VPSA_PREFILL_ARGS, rope, tile_split, split_ws);
     } else if (variant == 8) {
       hipLaunchKernelGGL((paged_prefill_kernel_v4<false, false>), grid, block, 98304, stream,
-                         VPSA_PREFILL_ARGS, rope);
+                         VPSA_PREFILL_ARGS, rope, tile_split, split_ws);
     } else if (variant == 5) {
       hipLaunchKernelGGL((paged_prefill_kernel_v3<true, 1>), grid, block, 98304, stream,
                          VPSA_PREFILL_ARGS);
@@ -1685,8 +1800,12 @@ VPSA_EXPORT int vpsa_paged_prefill_rope(const void* q, long q_stride, void* out,
       hipLaunchKernelGGL((paged_prefill_kernel_v3<false, 0>), grid, block, 98304, stream,
                          VPSA_PREFILL_ARGS);
     }
+    if (tile_split != nullptr && num_groups > 0)
+      hipLaunchKernelGGL(prefill_combine_kernel, dim3(num_groups, n_kv * (G / 4), 8), block, 0, stream,
+                         (const float*)split_ws, groups, (uint16_t*)out, out_stride, cu_q, n_q, n_kv);
     return 0;
   }
+  if (tile_split != nullptr) return -4;
   if (tile_rows != 32 * (4 / GP) || variant >= 4) return -2;
   dim3 grid(num_tiles, n_kv * ((G + GP - 1) / GP)), block(256);
   if (variant < 0) variant = many_tiles ? 3 : 2;

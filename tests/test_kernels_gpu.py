@@ -164,6 +164,60 @@ def test_paged_prefill_matches_reference(n_q, n_kv, variant):
     assert err < REL_TOL, err
 
 
+@pytest.mark.parametrize("variant", [-1, 8, 9, 10, 11])
+@pytest.mark.parametrize("rope", [False, True])
+def test_paged_prefill_key_range_splits_match_reference(variant, rope):
+    """A short work list in front of long contexts is cut into key ranges that run as workgroups
+    of their own and are merged by a second launch: a follow-up turn of 8 rows behind 21k cached
+    tokens, a 100-row chunk (two tiles, the first one whole) behind 5k, and a short sequence that
+    is not split, all in one launch.  Same result as the unsplit reference."""
+    torch.manual_seed(50)
+    n_q, n_kv, hd = 32, 8, 128
+    cases = [(8, 20992), (100, 5000), (40, 100)]
+    q_lens = [c[0] for c in cases]
+    ctx = [c[0] + c[1] for c in cases]
+    max_pages = (max(ctx) + ops.PAGE - 1) // ops.PAGE
+    pool = _v_offset_pool(sum((c + ops.PAGE - 1) // ops.PAGE for c in ctx) + 5, 1, n_kv, seed=51)
+    perm = torch.randperm(pool.shape[0] - 1, device=DEV)[: len(cases) * max_pages].to(torch.int32) + 1
+    bt = torch.zeros((len(cases), max_pages), dtype=torch.int32, device=DEV)
+    used = 0
+    for i, c in enumerate(ctx):
+        n = (c + ops.PAGE - 1) // ops.PAGE
+        bt[i, :n] = perm[used:used + n]
+        used += n
+    q = torch.randn(sum(q_lens), n_q * hd, device=DEV).to(BF)
+    cu = torch.tensor([0] + list(torch.tensor(q_lens).cumsum(0)), dtype=torch.int32, device=DEV)
+    ctx_t = torch.tensor(ctx, dtype=torch.int32, device=DEV)
+    scale = 1.0 / math.sqrt(hd)
+    cos_sin = ops.build_cos_sin(hd, max(ctx) + 1, 500000.0, device=DEV) if rope else None
+    out = torch.zeros_like(q)
+    prev = ops.set_prefill_variant(variant)
+    try:
+        rows = ops.prefill_tile_rows(q_lens, n_q, n_kv)
+        assert rows == 64
+        ts, tq = ops.build_prefill_tiles(q_lens, n_q, n_kv, rows, ctx)
+        cut = ops.plan_prefill_splits(ts, tq, q_lens, ctx, n_q, n_kv, rows)
+        assert cut is not None
+        ts, tq, split, groups, n_rec = cut
+        assert n_rec > 30 and len(groups) == 4 * 3  # both tiles of the 100-row chunk and the 8-row turn are cut
+        assert -1 in split[2::3], "the short sequence keeps its single entry"
+        ws = torch.full((n_rec * ops.prefill_split_record_bytes(n_q, n_kv) // 4,), float("nan"), device=DEV)
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)  # noqa: E731
+        ops.paged_prefill(q, out, pool, 0, bt, cu, ctx_t, i32(ts), i32(tq), n_q, n_kv, hd, scale, rows,
+                          rope=cos_sin, split=i32(split), split_ws=ws, groups=i32(groups))
+    finally:
+        ops.set_prefill_variant(prev)
+    torch.cuda.synchronize()
+    q_ref = q
+    if rope:  # the kernel rotated its query rows itself: rotate them for the reference
+        q_ref = q.clone()
+        pos = torch.cat([torch.arange(c - n, c, device=DEV, dtype=torch.int32) for n, c in zip(q_lens, ctx)])
+        ops.rope_and_cache(q_ref, pos, None, cos_sin, pool, 0, n_q, 0, hd, True)  # queries only, in place
+    out_ref = torch.zeros_like(q)
+    ref.paged_prefill(q_ref, out_ref, pool, 0, bt, cu, ctx_t, n_q, n_kv, hd, scale)
+    assert _rel_row_err(out, out_ref, n_q) < REL_TOL
+
+
 @pytest.mark.parametrize("variant", [-1, 0, 2, 4, 8, 10])
 def test_paged_prefill_skips_padding_of_a_fixed_size_work_list(variant):
     """A captured graph launches the kernel with a work list, a sequence table and a row count of

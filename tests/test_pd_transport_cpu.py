@@ -488,3 +488,43 @@ def test_stuck_rccl_receive_quarantines_its_pages():
     stuck.done = True
     recv.reserve([302], page_bytes)
     assert dec.bm.num_free() == free0 - 2  # the two quarantined pages are back, 301 and 302 are reserved
+
+
+def test_pushed_prompts_end_in_a_short_chunk(monkeypatch):
+    """Only the last chunk's pages travel after the prefill has ended, so a prompt whose pages are
+    pushed is cut so that its last chunk is short (here 64 tokens: 330 = 256 + 74, page-aligned),
+    even when the whole prompt would fit one step; a request that is not pushed runs whole."""
+    from vllm_production_stack_amd.engine.scheduler import Scheduler
+
+    monkeypatch.setattr(Scheduler, "PUSH_TAIL_TOKENS", 64)
+
+    async def go():
+        dec, dae, drunner, url = await _pd_pair()
+        pre = LLMEngine(EngineConfig(model="tiny-llama", device="cpu", dtype="float32", max_model_len=1024,
+                                     num_gpu_blocks_override=32, host="127.0.0.1", port=0, max_num_batched_tokens=512,
+                                     kv_transfer=KVTransferConfig("LMCacheConnectorV1", "kv_producer")))
+
+        def run(prompt, kvp):
+            sp = SamplingParams(max_tokens=1, temperature=0, ignore_eos=True)
+            req = pre.add_request(prompt, sp, kv_transfer_params=kvp)
+            rows, r0 = [], pre.prof["rows"]
+            while pre.has_work():
+                pre.step()
+                rows.append(pre.prof["rows"] - r0)
+                r0 = pre.prof["rows"]
+            if kvp:
+                pre.connector.push_future(req.request_id).result(30)
+            return rows, req.output_ids
+
+        loop = asyncio.get_running_loop()
+        pushed, out_a = await loop.run_in_executor(None, run, _prompt(seed=31), {"do_remote_decode": True, "decode_target": url})
+        plain, out_b = await loop.run_in_executor(None, run, _prompt(seed=32), None)
+        assert pushed == [256, 74], pushed
+        assert plain == [330], plain
+        same, cached = await _decode_matches(dae, _prompt(seed=31))
+        assert same and cached == 320
+        await drunner.cleanup()
+        dae.stop()
+        pre.shutdown()
+
+    asyncio.run(go())

@@ -42,6 +42,7 @@ _GRAPH_BUCKETS = [1, 2, 4, 8, 12, 16, 24, 32, 40, 48, 64, 80, 96, 128, 160, 192,
 # sequences; larger prefills run eagerly (their GPU time dwarfs the launches).
 _PREFILL_ROW_BUCKETS = [64, 128, 256, 512]
 _PREFILL_GRAPH_SEQS = 8
+_PREFILL_GRAPH_SPLIT_RECORDS = 72  # partial records a prefill graph has room for (1 MiB each for Llama-3-8B)
 
 
 class ModelRunner:
@@ -301,6 +302,14 @@ class ModelRunner:
             if self.device.type == "cuda":
                 rows = ops.prefill_tile_rows(q_lens, self.model.n_q, self.model.n_kv)
                 ts, tq = ops.build_prefill_tiles(q_lens, self.model.n_q, self.model.n_kv, rows, plan["pre_ctx"])
+                cut = ops.plan_prefill_splits(ts, tq, q_lens, plan["pre_ctx"], self.model.n_q, self.model.n_kv, rows)
+                if cut is not None:  # few tiles, long contexts: the key ranges run as workgroups of their own
+                    ts, tq, split, groups, n_rec = cut
+                    meta.pre_split = self._to_dev(split, torch.int32)
+                    meta.pre_split_groups = self._to_dev(groups, torch.int32)
+                    meta.pre_split_ws = torch.empty(
+                        n_rec * ops.prefill_split_record_bytes(self.model.n_q, self.model.n_kv) // 4,
+                        dtype=torch.float32, device=self.device)
                 meta.pre_tile_rows = rows
                 meta.pre_tile_seq = self._to_dev(ts, torch.int32)
                 meta.pre_tile_q0 = self._to_dev(tq, torch.int32)
@@ -582,16 +591,21 @@ class ModelRunner:
         S = _PREFILL_GRAPH_SEQS
         mp = self.max_pages_per_seq
         tile = ops.prefill_tile_rows([rows], self.model.n_q, self.model.n_kv)
-        n_tiles = rows // tile + S  # every sequence may end in a partial tile
-        # int32: pos[rows] | cu_q[S + 1] | ctx[S] | tile_seq[n_tiles] | tile_q0[n_tiles], each part
-        # starting on a 16-byte boundary
+        base_tiles = rows // tile + S  # every sequence may end in a partial tile
+        # room for key-range splits of a short work list (ops.plan_prefill_splits)
+        max_records = _PREFILL_GRAPH_SPLIT_RECORDS if ops.prefill_splits_supported(self.model.n_q, self.model.n_kv, tile) else 0
+        n_tiles = base_tiles + max_records
+        # int32: pos[rows] | cu_q[S + 1] | ctx[S] | tile_seq[n_tiles] | tile_q0[n_tiles] |
+        # split[n_tiles][3] | groups[base_tiles][4], each part starting on a 16-byte boundary
         def up4(n):
             return (n + 3) // 4 * 4
         o_pos, o_cu = 0, up4(rows)
         o_ctx = o_cu + up4(S + 1)
         o_ts = o_ctx + up4(S)
         o_tq = o_ts + up4(n_tiles)
-        n32 = o_tq + up4(n_tiles)
+        o_sp = o_tq + up4(n_tiles)
+        o_gr = o_sp + up4(3 * n_tiles)
+        n32 = o_gr + up4(4 * base_tiles)
         # int64: ids[rows] | slots[rows] | logits_rows[S]
         n64 = 2 * rows + S
         d32 = torch.zeros(n32, dtype=torch.int32, device=dev)
@@ -608,13 +622,27 @@ class ModelRunner:
         bt = torch.zeros((S, mp), dtype=torch.int32, device=dev)
         st = {"rows": rows, "tile": tile, "n_tiles": n_tiles, "d32": d32, "d64": d64, "h32": h32, "h64": h64,
               "hbt": hbt, "bt": bt, "n32": h32.numpy(), "n64": h64.numpy(), "nbt": hbt.numpy(),
-              "off": (o_pos, o_cu, o_ctx, o_ts, o_tq), "copied": torch.cuda.Event()}
+              "off": (o_pos, o_cu, o_ctx, o_ts, o_tq), "o_sp": o_sp, "o_gr": o_gr, "base_tiles": base_tiles,
+              "max_records": max_records, "copied": torch.cuda.Event()}
+        split_ws = None
+        if max_records:
+            split_ws = torch.empty(max_records * ops.prefill_split_record_bytes(self.model.n_q, self.model.n_kv) // 4,
+                                   dtype=torch.float32, device=dev)
+            for i in range(n_tiles):  # (first key tile, end, record): whole range, no record
+                h32[o_sp + 3 * i + 1] = 1 << 30
+                h32[o_sp + 3 * i + 2] = -1
+            d32.copy_(h32)
         ids = d64[:rows]
         meta = BatchMeta(positions=d32[o_pos:o_pos + rows], slots=d64[rows:2 * rows], num_decode=0,
                          num_prefill_seqs=S, pre_block_tables=bt, pre_cu_q=d32[o_cu:o_cu + S + 1],
                          pre_ctx_lens=d32[o_ctx:o_ctx + S], pre_tile_seq=d32[o_ts:o_ts + n_tiles],
                          pre_tile_q0=d32[o_tq:o_tq + n_tiles], pre_tile_rows=tile,
                          logits_rows=d64[2 * rows:2 * rows + S], pre_padded=True)
+        if max_records:
+            meta.pre_split = d32[o_sp:o_sp + 3 * n_tiles]
+            meta.pre_split_groups = d32[o_gr:o_gr + 4 * base_tiles]
+            meta.pre_split_ws = split_ws
+            st["split_ws"] = split_ws
 
         def run():
             hidden = self.model.forward(ids, self.pool, meta)
@@ -678,6 +706,17 @@ class ModelRunner:
                 sample_seqs.append(s)
         n32[o_cu + len(prefills) + 1:o_cu + S + 1] = row  # the unused sequences are empty
         ts, tq = ops.build_prefill_tiles(q_lens, self.model.n_q, self.model.n_kv, st["tile"], ctx)
+        if st["max_records"]:
+            o_sp, o_gr, nt = st["o_sp"], st["o_gr"], st["n_tiles"]
+            sp = n32[o_sp:o_sp + 3 * nt].reshape(nt, 3)
+            sp[:, 0], sp[:, 1], sp[:, 2] = 0, 1 << 30, -1
+            n32[o_gr:o_gr + 4 * st["base_tiles"]] = 0
+            cut = ops.plan_prefill_splits(ts, tq, q_lens, ctx, self.model.n_q, self.model.n_kv, st["tile"],
+                                          max_entries=nt, max_records=st["max_records"])
+            if cut is not None:
+                ts, tq, split, groups, _n_rec = cut
+                n32[o_sp:o_sp + len(split)] = split
+                n32[o_gr:o_gr + len(groups)] = groups
         n32[o_ts:o_ts + len(ts)] = ts
         n32[o_tq:o_tq + len(tq)] = tq
         st["d64"].copy_(st["h64"], non_blocking=True)

@@ -31,6 +31,11 @@ class BatchMeta:
     pre_tile_seq: torch.Tensor | None = None
     pre_tile_q0: torch.Tensor | None = None
     pre_tile_rows: int | None = None  # tile height the work list was built for
+    # key-range splits of a short work list (ops.plan_prefill_splits): int32 [entries, 3], the fp32
+    # workspace of the partial records, int32 [groups, 4]; None = every entry walks all its keys
+    pre_split: torch.Tensor | None = None
+    pre_split_ws: torch.Tensor | None = None
+    pre_split_groups: torch.Tensor | None = None
     # the batch is padded to a captured graph's fixed size: rows past the real ones belong to no
     # sequence (slot -1, no tile covers them), so the attention output is zeroed first and what
     # flows on from those rows stays finite

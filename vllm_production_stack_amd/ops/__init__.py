@@ -36,9 +36,10 @@ def _kernels():
             "vpsa_stream_gemm_splits", "vpsa_set_stream_targets", "vpsa_rans_encode", "vpsa_rans_pack",
             "vpsa_rans_decode", "vpsa_sample", "vpsa_grouped_gemm", "vpsa_packed_gemm",
             "vpsa_packed_gemm_splits", "vpsa_set_packed_target", "vpsa_dense_decode_attention", "vpsa_dense_attention",
-            "vpsa_tile_gemm", "vpsa_tile_gemm_debug",
+            "vpsa_tile_gemm", "vpsa_tile_gemm_debug", "vpsa_paged_prefill_split",
         ):
             getattr(lib, name).restype = c_int
+        lib.vpsa_prefill_split_record_bytes.restype = c_long
         if os.environ.get("VPSA_PREFILL_VARIANT"):  # pin one prefill kernel for A/B runs
             lib.vpsa_set_prefill_variant(c_int(int(os.environ["VPSA_PREFILL_VARIANT"])))
         _lib = lib
@@ -221,7 +222,8 @@ def _attention_block(qkv, pool, layer, meta, n_q, n_kv, d, scale, cos_sin, rotar
     if meta.num_prefill_seqs > 0:
         paged_prefill(q[nd:], out[nd:], pool, layer, meta.pre_block_tables, meta.pre_cu_q, meta.pre_ctx_lens,
                       meta.pre_tile_seq, meta.pre_tile_q0, n_q, n_kv, d, scale, meta.pre_tile_rows,
-                      rope=cos_sin if fuse else None)
+                      rope=cos_sin if fuse else None, split=getattr(meta, "pre_split", None),
+                      split_ws=getattr(meta, "pre_split_ws", None), groups=getattr(meta, "pre_split_groups", None))
     return out
 
 
@@ -285,8 +287,75 @@ def build_prefill_tiles(q_lens, n_q, n_kv, rows=None, ctx_lens=None):
     return seqs, q0s
 
 
+# Few query tiles in front of long contexts (one new turn behind a 21k-token history: 8 workgroups
+# that each walk 330 key tiles alone, 10 ms on a 256-CU chip): the key range of such entries is cut
+# into pieces that run as workgroups of their own and leave partials for a merge pass.
+SPLIT_TARGET_WGS = 512      # workgroups aimed for after splitting (two per CU)
+SPLIT_MIN_KEY_TILES = 8     # a piece is at least this long (the kernel needs >= 3 in the last one)
+PREFILL_SPLITS = os.environ.get("VPSA_PREFILL_SPLITS", "1") != "0"
+
+
+def prefill_split_record_bytes(n_q: int, n_kv: int) -> int:
+    return int(_kernels().vpsa_prefill_split_record_bytes(c_int(n_q), c_int(n_kv)))
+
+
+def prefill_splits_supported(n_q: int, n_kv: int, rows: int) -> bool:
+    """Only the 64-row kernels for GQA groups of 4 and multiples take split work lists."""
+    return PREFILL_SPLITS and rows == 64 and n_kv > 0 and n_q % n_kv == 0 and (n_q // n_kv) % 4 == 0
+
+
+def plan_prefill_splits(seqs, q0s, q_lens, ctx_lens, n_q, n_kv, rows, max_entries=None, max_records=None):
+    """Cut the key ranges of a short work list.  Returns None when nothing is to be split, else
+    (seqs, q0s, split, groups, n_records): the expanded work list, ``split`` = 3 ints per entry
+    (first key tile, end key tile, partial record or -1), ``groups`` = 4 ints per split tile
+    (sequence, first row, first record, records)."""
+    if not prefill_splits_supported(n_q, n_kv, rows) or not seqs:
+        return None
+    head_groups = n_kv * (n_q // n_kv // 4)
+    if len(seqs) * head_groups >= TILE_CUS:
+        return None
+    kts = []
+    for s, q0 in zip(seqs, q0s):
+        last_row = min(q0 + rows - 1, q_lens[s] - 1)
+        kts.append((ctx_lens[s] - q_lens[s] + last_row) // PAGE + 1)
+    total = sum(kts)
+    want = max(len(seqs), SPLIT_TARGET_WGS // head_groups)
+    if max_entries is not None:
+        want = min(want, max_entries)
+    if max_records is not None:
+        want = min(want, max_records)
+    piece = max(SPLIT_MIN_KEY_TILES, -(-total // want))
+    counts = [max(1, kt // piece) for kt in kts]
+    if max(counts) == 1:
+        return None
+    # never more entries / records than the caller's fixed-size buffers hold
+    while ((max_entries is not None and sum(counts) > max_entries)
+           or (max_records is not None and sum(c for c in counts if c > 1) > max_records)):
+        i = max(range(len(counts)), key=lambda j: counts[j])
+        counts[i] -= 1
+    seqs2, q0s2, split, groups = [], [], [], []
+    rec = 0
+    for s, q0, kt, c in zip(seqs, q0s, kts, counts):
+        if c == 1:
+            seqs2.append(s)
+            q0s2.append(q0)
+            split += [0, kt, -1]
+            continue
+        groups += [s, q0, rec, c]
+        base, extra = divmod(kt, c)
+        k0 = 0
+        for j in range(c):
+            k1 = k0 + base + (1 if j < extra else 0)
+            seqs2.append(s)
+            q0s2.append(q0)
+            split += [k0, k1, rec]
+            rec += 1
+            k0 = k1
+    return seqs2, q0s2, split, groups, rec
+
+
 def paged_prefill(q, out, pool, layer, block_tables, cu_q, ctx_lens, tile_seq, tile_q0, n_q, n_kv,
-                  head_dim, scale, tile_rows=None, rope=None):
+                  head_dim, scale, tile_rows=None, rope=None, split=None, split_ws=None, groups=None):
     """``tile_rows``: the tile height ``tile_seq`` / ``tile_q0`` were built for (default: the
     32-row-wave layout of the first two kernel generations).  ``rope``: the [position, head_dim]
     fp32 cos / sin table when ``q`` holds unrotated rows (``prefill_fuses_rope`` says whether the
@@ -303,12 +372,18 @@ def paged_prefill(q, out, pool, layer, block_tables, cu_q, ctx_lens, tile_seq, t
         tile_rows = 32 * (4 // min(n_q // n_kv, 4))
     base = pool.data_ptr() + layer * pool.stride(1) * 2
     assert rope is None or (rope.dtype == torch.float32 and rope.is_contiguous() and rope.shape[1] == head_dim)
-    rc = _kernels().vpsa_paged_prefill_rope(
+    if split is not None:
+        # split [entries][3], groups [n][4] (int32 on the device), split_ws fp32 with room for every record
+        assert split.dtype == torch.int32 and split.numel() == 3 * tile_seq.numel() and split.is_contiguous()
+        assert groups.dtype == torch.int32 and groups.numel() % 4 == 0 and groups.is_contiguous()
+        assert split_ws.dtype == torch.float32 and split_ws.is_contiguous()
+    rc = _kernels().vpsa_paged_prefill_split(
         _p(q), c_long(q.stride(0)), _p(out), c_long(out.stride(0)), c_void_p(base),
         c_long(pool.stride(0)), c_long(pool.stride(2)), _p(block_tables),
         c_int(block_tables.stride(0)), _p(cu_q), _p(ctx_lens), _p(tile_seq), _p(tile_q0),
         c_int(tile_seq.numel()), c_int(ctx_lens.numel()), c_int(tile_rows), c_int(n_q), c_int(n_kv),
-        c_float(scale), _p(rope), _stream())
+        c_float(scale), _p(rope), _p(split), _p(split_ws), _p(groups),
+        c_int(0 if groups is None else groups.numel() // 4), _stream())
     _check(rc, "paged_prefill")
 
 
