@@ -562,3 +562,40 @@ def test_prefill_graph_handles_eight_sequences_and_falls_back_beyond():
     assert eng.runner.step_kinds["eager"] == 1
     # the same prompts give the same answers on either path
     assert [r.output_ids for r in few] == [r.output_ids for r in many[:8]]
+
+
+def test_follow_up_turn_behind_a_long_cached_prefix_splits_its_key_range(monkeypatch):
+    """A short new turn behind a long cached history is one query tile: its key range is cut into
+    pieces that run as workgroups of their own (captured graph and eager path alike).  Logits must
+    be those of the unsplit kernel, and the planner must really have cut."""
+    from vllm_production_stack_amd import ops
+
+    history = prompts(1, 1500, seed=60)[0]
+    turn = history + prompts(1, 11, seed=61)[0]
+    sp = SamplingParams(max_tokens=4, temperature=0, ignore_eos=True)
+    planned = []
+    orig = ops.plan_prefill_splits
+
+    def spy(*a, **kw):
+        r = orig(*a, **kw)
+        planned.append(None if r is None else r[4])
+        return r
+
+    monkeypatch.setattr(ops, "plan_prefill_splits", spy)
+
+    def run(eng):
+        eng.generate([history], copy.deepcopy(sp))  # fills the prefix cache
+        seen = _capture_logits(eng)
+        out = eng.generate([turn], copy.deepcopy(sp))
+        return out, torch.cat(seen)
+
+    got_g, log_g = run(gpu_engine("tiny-llama-gqa", pages=96, budget=2048))
+    assert any(p for p in planned), planned  # records were planned for the follow-up turn
+    n_graph = len(planned)
+    got_e, log_e = run(gpu_engine("tiny-llama-gqa", pages=96, budget=2048, enforce_eager=True))
+    assert any(p for p in planned[n_graph:])
+    monkeypatch.setattr(ops, "PREFILL_SPLITS", False)
+    got_u, log_u = run(gpu_engine("tiny-llama-gqa", pages=96, budget=2048, enforce_eager=True))
+    cos = torch.nn.functional.cosine_similarity
+    assert cos(log_g[:1], log_u[:1]).item() > 0.9995 and cos(log_e[:1], log_u[:1]).item() > 0.9995
+    assert got_e == got_u or cos(log_e, log_u).min().item() > 0.999
