@@ -252,3 +252,59 @@ def test_ipc_safe_size_avoids_the_sizes_hipipc_cannot_map():
         got = ipc_safe_size(want)
         assert got <= want and want - got <= 2 * G + (2 << 20) and (got & 0xFFFFFFFF) < 0x80000000 and got % 4096 == 0
     assert ipc_safe_size(2 * G) == 2 * G - (2 << 20)
+
+
+def test_prefill_split_planner_covers_every_key_tile_once():
+    """The planner of key-range splits (short work lists in front of long contexts): pieces of a
+    tile are contiguous, cover [0, key tiles) exactly, are at least 8 tiles long (the kernel needs
+    3 in the last one), record numbers are consecutive, caps of fixed-size graph buffers hold, and
+    nothing is cut when the list already fills the chip or the contexts are short."""
+    import random
+
+    from vllm_production_stack_amd import ops
+
+    rng = random.Random(3)
+    cut_some = False
+    for _ in range(300):
+        n_seqs = rng.randint(1, 8)
+        q_lens = [rng.randint(1, 200) for _ in range(n_seqs)]
+        ctx = [q + rng.choice((0, 100, 3000, 21000, 60000)) for q in q_lens]
+        n_q, n_kv = rng.choice(((32, 8), (8, 2), (64, 8), (16, 4)))
+        seqs, q0s = [], []
+        for s in range(n_seqs):
+            for q0 in range((q_lens[s] - 1) // 64 * 64, -1, -64):
+                seqs.append(s)
+                q0s.append(q0)
+        caps = rng.choice((None, (len(seqs) + 72, 72), (len(seqs) + 4, 4)))
+        r = ops.plan_prefill_splits(seqs, q0s, q_lens, ctx, n_q, n_kv, 64,
+                                    max_entries=caps and caps[0], max_records=caps and caps[1])
+        if r is None:
+            continue
+        cut_some = True
+        seqs2, q0s2, split, groups, n_rec = r
+        assert len(split) == 3 * len(seqs2) == 3 * len(q0s2)
+        if caps:
+            assert len(seqs2) <= caps[0] and n_rec <= caps[1]
+        by_tile: dict = {}
+        for i, (s, q0) in enumerate(zip(seqs2, q0s2)):
+            by_tile.setdefault((s, q0), []).append(split[3 * i:3 * i + 3])
+        assert sorted(by_tile) == sorted(zip(seqs, q0s))
+        recs = []
+        for (s, q0), pieces in by_tile.items():
+            kt = (ctx[s] - q_lens[s] + min(q0 + 63, q_lens[s] - 1)) // 64 + 1
+            assert pieces[0][0] == 0 and pieces[-1][1] == kt
+            for a, b in zip(pieces, pieces[1:]):
+                assert a[1] == b[0]
+            if len(pieces) == 1:
+                assert pieces[0][2] == -1
+            else:
+                assert all(p[1] - p[0] >= 8 for p in pieces)
+                recs += [p[2] for p in pieces]
+                g = [groups[j:j + 4] for j in range(0, len(groups), 4) if groups[j:j + 2] == [s, q0]]
+                assert g == [[s, q0, pieces[0][2], len(pieces)]]
+        assert sorted(recs) == list(range(n_rec))
+    assert cut_some
+    # a list that fills the chip, and short contexts, stay as they are
+    assert ops.plan_prefill_splits(list(range(40)), [0] * 40, [30] * 40, [21000] * 40, 32, 8, 64) is None
+    assert ops.plan_prefill_splits([0], [0], [8], [300], 32, 8, 64) is None
+    assert ops.plan_prefill_splits([0], [0], [8], [21000], 12, 4, 64) is None  # group ratio 3: no 64-row kernel
