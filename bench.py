@@ -478,6 +478,15 @@ async def rank_main(a: argparse.Namespace) -> None:
         dist.init_process_group("gloo")
         gloo = dist.group.WORLD
     ctx = {"rank": rank, "world": world, "n": n, "on_gpu": on_gpu, "gloo": gloo}
+
+    async def heartbeat():
+        # a run of several minutes that prints nothing looks hung to whatever is watching it
+        t0 = time.time()
+        while True:
+            await asyncio.sleep(30)
+            print(f"[bench] running, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+
+    beat = asyncio.create_task(heartbeat()) if rank == 0 else None
     try:
         off = KVOffloadConfig(local_cpu=a.cpu_offload_gb > 0, max_local_cpu_gb=a.cpu_offload_gb)
         head = await run_phase(
@@ -550,6 +559,8 @@ async def rank_main(a: argparse.Namespace) -> None:
                         "per_replica": ref["per_replica"]}
             print(json.dumps(result), file=result_out, flush=True)
     finally:
+        if beat is not None:
+            beat.cancel()
         if world > 1:
             dist.destroy_process_group()
 

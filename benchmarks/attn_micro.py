@@ -3,6 +3,7 @@
 
 Cases (one JSON line each):
   prefill_cold   one sequence, an 8192-token chunk behind an 8192-token cached prefix
+  prefill_split  part-filled launches, whole vs. cut along the key range (off by default)
   prefill_warm   40 sequences, 128 new tokens each behind ~21k cached tokens (a follow-up turn)
   decode         40 sequences, one token each, ~21.5k-token contexts (distinct pages)
 
@@ -93,6 +94,57 @@ def prefill_case(name: str, n_seqs: int, q_len: int, prefix: int, iters: int,
     return res
 
 
+def split_case(n_seqs: int, q_len: int, prefix: int, iters: int) -> dict:
+    """The automatic kernel on a work list as built vs. the same list with the key ranges cut by
+    ``ops.plan_prefill_splits`` (what the engine runs)."""
+    ctx = prefix + q_len
+    pages_per_seq = (ctx + PAGE - 1) // PAGE
+    pool = make_pool(n_seqs * pages_per_seq + 1)
+    g = torch.Generator().manual_seed(1)
+    bt = torch.randperm(n_seqs * pages_per_seq, generator=g).view(n_seqs, pages_per_seq).to(torch.int32).to(DEV)
+    q = torch.randn((n_seqs * q_len, N_Q * HD), device=DEV).to(torch.bfloat16)
+    out = torch.empty_like(q)
+    out2 = torch.empty_like(q)
+    cu = torch.arange(0, (n_seqs + 1) * q_len, q_len, dtype=torch.int32, device=DEV)
+    ctxs = torch.full((n_seqs,), ctx, dtype=torch.int32, device=DEV)
+    scale = HD ** -0.5
+    q_lens, ctx_lens = [q_len] * n_seqs, [ctx] * n_seqs
+    rows = ops.prefill_tile_rows(q_lens, N_Q, N_KV)
+    ts, tq = ops.build_prefill_tiles(q_lens, N_Q, N_KV, rows, ctx_lens)
+    res = {"case": "prefill_split", "n_seqs": n_seqs, "q_len": q_len, "prefix": prefix,
+           "entries": len(ts)}
+    dev = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    d_ts, d_tq = dev(ts), dev(tq)
+    keys = sum(prefix + i + 1 for i in range(q_len)) * n_seqs
+    flops = 4.0 * keys * HD * N_Q
+
+    def whole():
+        ops.paged_prefill(q, out, pool, 0, bt, cu, ctxs, d_ts, d_tq, N_Q, N_KV, HD, scale, rows)
+    cut = ops.plan_prefill_splits(ts, tq, q_lens, ctx_lens, N_Q, N_KV, rows)
+    runs = {"whole": whole}
+    if cut is not None:
+        ts2, tq2, split, groups, n_rec = cut
+        d_ts2, d_tq2, d_split, d_groups = dev(ts2), dev(tq2), dev(split), dev(groups)
+        ws = torch.empty(n_rec * ops.prefill_split_record_bytes(N_Q, N_KV) // 4, dtype=torch.float32, device=DEV)
+        pieces = [split[3 * i + 1] - split[3 * i] for i in range(len(ts2))]
+        res.update(cut_entries=len(ts2), records=n_rec, piece_tiles=[min(pieces), max(pieces)])
+
+        def planned():
+            ops.paged_prefill(q, out2, pool, 0, bt, cu, ctxs, d_ts2, d_tq2, N_Q, N_KV, HD, scale, rows,
+                              split=d_split, split_ws=ws, groups=d_groups)
+        runs["planned"] = planned
+    samples = {k: [] for k in runs}
+    for _ in range(3):
+        for k, fn in runs.items():
+            samples[k].append(timed(fn, iters))
+    for k in runs:
+        ms = sorted(samples[k])[1]
+        res[k] = {"ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 1)}
+    if cut is not None:
+        res["max_abs_diff"] = float((out.float() - out2.float()).abs().max())
+    return res
+
+
 def decode_case(n_seqs: int, ctx: int, iters: int) -> dict:
     pages_per_seq = (ctx + PAGE - 1) // PAGE
     pool = make_pool(n_seqs * pages_per_seq + 1)
@@ -141,6 +193,10 @@ def main():
         print(json.dumps(prefill_case("prefill_bulk", 8, 4096, 8192, a.iters, variants)), flush=True)
     if "prefill_warm" in cases:
         print(json.dumps(prefill_case("prefill_warm", 40, 128, 21000, a.iters, variants)), flush=True)
+    if "prefill_split" in cases:  # part-filled launches: whole work list vs. planned key-range cuts
+        for n, ql, pre in ((1, 64, 21000), (1, 150, 21000), (4, 150, 21000), (12, 150, 21000),
+                           (20, 150, 21000), (40, 128, 21000), (1, 1024, 8192), (1, 2048, 18000)):
+            print(json.dumps(split_case(n, ql, pre, a.iters)), flush=True)
     if "decode" in cases:
         print(json.dumps(decode_case(40, 21500, a.iters)), flush=True)
 

@@ -266,9 +266,10 @@ def test_prefill_split_planner_covers_every_key_tile_once():
     rng = random.Random(3)
     cut_some = False
     for _ in range(300):
-        n_seqs = rng.randint(1, 8)
+        n_seqs = rng.choice((rng.randint(1, 8), rng.randint(9, 48)))
         q_lens = [rng.randint(1, 200) for _ in range(n_seqs)]
-        ctx = [q + rng.choice((0, 100, 3000, 21000, 60000)) for q in q_lens]
+        shared = rng.choice((None, 21000))  # equal histories: the part-filled last round is what gets cut
+        ctx = [q + (shared or rng.choice((0, 100, 3000, 21000, 60000))) for q in q_lens]
         n_q, n_kv = rng.choice(((32, 8), (8, 2), (64, 8), (16, 4)))
         seqs, q0s = [], []
         for s in range(n_seqs):
@@ -304,7 +305,11 @@ def test_prefill_split_planner_covers_every_key_tile_once():
                 assert g == [[s, q0, pieces[0][2], len(pieces)]]
         assert sorted(recs) == list(range(n_rec))
     assert cut_some
-    # a list that fills the chip, and short contexts, stay as they are
-    assert ops.plan_prefill_splits(list(range(40)), [0] * 40, [30] * 40, [21000] * 40, 32, 8, 64) is None
+    # lists that fill the chip in whole rounds, and short contexts, stay as they are
+    for n in (32, 64):
+        assert ops.plan_prefill_splits(list(range(n)), [0] * n, [30] * n, [21000] * n, 32, 8, 64) is None
+    # 40 x 8 workgroups would run as one full round and a quarter-filled second
+    cut = ops.plan_prefill_splits(list(range(40)), [0] * 40, [30] * 40, [21000] * 40, 32, 8, 64)
+    assert cut is not None and len(cut[0]) * 8 % 256 <= 8 * 8
     assert ops.plan_prefill_splits([0], [0], [8], [300], 32, 8, 64) is None
     assert ops.plan_prefill_splits([0], [0], [8], [21000], 12, 4, 64) is None  # group ratio 3: no 64-row kernel

@@ -18,7 +18,7 @@ SP = SamplingParams(max_tokens=8, temperature=0, ignore_eos=True)
 
 
 def gpu_engine(model="tiny-llama-gqa", pages=96, **kw):
-    cfg = EngineConfig(model=model, device="cuda", dtype="bfloat16", max_model_len=2048,
+    cfg = EngineConfig(model=model, device="cuda", dtype="bfloat16", max_model_len=kw.pop("max_len", 2048),
                        max_num_seqs=kw.pop("seqs", 16), max_num_batched_tokens=kw.pop("budget", 512),
                        num_gpu_blocks_override=pages, port=0, **kw)
     return LLMEngine(cfg)
@@ -570,7 +570,7 @@ def test_follow_up_turn_behind_a_long_cached_prefix_splits_its_key_range(monkeyp
     be those of the unsplit kernel, and the planner must really have cut."""
     from vllm_production_stack_amd import ops
 
-    history = prompts(1, 1500, seed=60)[0]
+    history = prompts(1, 5000, seed=60)[0]
     turn = history + prompts(1, 11, seed=61)[0]
     sp = SamplingParams(max_tokens=4, temperature=0, ignore_eos=True)
     planned = []
@@ -589,13 +589,13 @@ def test_follow_up_turn_behind_a_long_cached_prefix_splits_its_key_range(monkeyp
         out = eng.generate([turn], copy.deepcopy(sp))
         return out, torch.cat(seen)
 
-    got_g, log_g = run(gpu_engine("tiny-llama-gqa", pages=96, budget=2048))
+    got_g, log_g = run(gpu_engine("tiny-llama-gqa", pages=128, max_len=6144, budget=2048))
     assert any(p for p in planned), planned  # records were planned for the follow-up turn
     n_graph = len(planned)
-    got_e, log_e = run(gpu_engine("tiny-llama-gqa", pages=96, budget=2048, enforce_eager=True))
+    got_e, log_e = run(gpu_engine("tiny-llama-gqa", pages=128, max_len=6144, budget=2048, enforce_eager=True))
     assert any(p for p in planned[n_graph:])
     monkeypatch.setattr(ops, "PREFILL_SPLITS", False)
-    got_u, log_u = run(gpu_engine("tiny-llama-gqa", pages=96, budget=2048, enforce_eager=True))
+    got_u, log_u = run(gpu_engine("tiny-llama-gqa", pages=128, max_len=6144, budget=2048, enforce_eager=True))
     cos = torch.nn.functional.cosine_similarity
     assert cos(log_g[:1], log_u[:1]).item() > 0.9995 and cos(log_e[:1], log_u[:1]).item() > 0.9995
     assert got_e == got_u or cos(log_e, log_u).min().item() > 0.999

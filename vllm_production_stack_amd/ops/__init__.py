@@ -287,11 +287,18 @@ def build_prefill_tiles(q_lens, n_q, n_kv, rows=None, ctx_lens=None):
     return seqs, q0s
 
 
-# Few query tiles in front of long contexts (one new turn behind a 21k-token history: 8 workgroups
-# that each walk 330 key tiles alone, 10 ms on a 256-CU chip): the key range of such entries is cut
-# into pieces that run as workgroups of their own and leave partials for a merge pass.
-SPLIT_TARGET_WGS = 512      # workgroups aimed for after splitting (two per CU)
+# Work lists that leave the chip part-filled are cut along the key range: one new turn behind a
+# 21k-token history is 8 workgroups that each walk 330 key tiles alone (10 ms on a 256-CU chip), and
+# 288 equal workgroups run as one full round and a nearly empty second.  The pieces run as
+# workgroups of their own and leave partials for a merge pass.  One workgroup occupies a CU (96 KiB
+# of LDS), so plans are priced in rounds of TILE_CUS workgroups.
 SPLIT_MIN_KEY_TILES = 8     # a piece is at least this long (the kernel needs >= 3 in the last one)
+SPLIT_MAX_ROUNDS = 3        # longer lists lose at most a quarter of a round and are left alone
+SPLIT_CANDIDATES = 8        # round counts tried, starting at the list's own
+SPLIT_WG_OVERHEAD = 10.0    # a workgroup's prologue + epilogue, in key-tile times (measured: 7 rounds
+                            # of 55-tile pieces take 62 tile times each on a full chip)
+SPLIT_MERGE_COST = 25.0     # the merge launch, in key-tile times
+SPLIT_RECORD_COST = 0.15    # writing + reading one partial record, in key-tile times
 PREFILL_SPLITS = os.environ.get("VPSA_PREFILL_SPLITS", "1") != "0"
 
 
@@ -304,38 +311,85 @@ def prefill_splits_supported(n_q: int, n_kv: int, rows: int) -> bool:
     return PREFILL_SPLITS and rows == 64 and n_kv > 0 and n_q % n_kv == 0 and (n_q // n_kv) % 4 == 0
 
 
+def _whole_cost(kts, head_groups):
+    """Modelled time of the uncut list in key-tile times.  Workgroups start longest first, so the
+    chip stays full until the last, partial round, which is made of the shortest entries."""
+    total = sum(kts) + SPLIT_WG_OVERHEAD * len(kts)
+    wgs = len(kts) * head_groups
+    tail = (TILE_CUS - wgs % TILE_CUS) % TILE_CUS / TILE_CUS * (min(kts) + SPLIT_WG_OVERHEAD)
+    return max(max(kts) + SPLIT_WG_OVERHEAD, total * head_groups / TILE_CUS + tail)
+
+
+def _split_counts(lengths, budget):
+    """``lengths``: {key tiles: entries of that length}.  Pieces per entry of each length so that
+    the longest piece is as short as ``budget`` entries in all allow; None when the budget does not
+    cover the list."""
+    def entries(piece):
+        return sum(m * max(1, min(-(-kt // piece), kt // SPLIT_MIN_KEY_TILES)) for kt, m in lengths.items())
+    lo, hi = SPLIT_MIN_KEY_TILES, max(lengths)
+    if entries(hi) > budget:
+        return None
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if entries(mid) <= budget:
+            hi = mid
+        else:
+            lo = mid + 1
+    return {kt: max(1, min(-(-kt // lo), kt // SPLIT_MIN_KEY_TILES)) for kt in lengths}
+
+
 def plan_prefill_splits(seqs, q0s, q_lens, ctx_lens, n_q, n_kv, rows, max_entries=None, max_records=None):
-    """Cut the key ranges of a short work list.  Returns None when nothing is to be split, else
-    (seqs, q0s, split, groups, n_records): the expanded work list, ``split`` = 3 ints per entry
-    (first key tile, end key tile, partial record or -1), ``groups`` = 4 ints per split tile
-    (sequence, first row, first record, records)."""
+    """Cut the key ranges of a work list that would leave the chip part-filled.  Returns None when
+    nothing is to be split, else (seqs, q0s, split, groups, n_records): the expanded work list,
+    ``split`` = 3 ints per entry (first key tile, end key tile, partial record or -1), ``groups`` =
+    4 ints per split tile (sequence, first row, first record, records).
+
+    The uncut list is priced with the chip kept full (what longest-first dispatch achieves), a plan
+    as whole rounds of its longest piece: a cut has to win against the better case of leaving the
+    list alone."""
     if not prefill_splits_supported(n_q, n_kv, rows) or not seqs:
         return None
     head_groups = n_kv * (n_q // n_kv // 4)
-    if len(seqs) * head_groups >= TILE_CUS:
+    if len(seqs) * head_groups > SPLIT_MAX_ROUNDS * TILE_CUS:
         return None
     kts = []
     for s, q0 in zip(seqs, q0s):
         last_row = min(q0 + rows - 1, q_lens[s] - 1)
         kts.append((ctx_lens[s] - q_lens[s] + last_row) // PAGE + 1)
-    total = sum(kts)
-    want = max(len(seqs), SPLIT_TARGET_WGS // head_groups)
-    if max_entries is not None:
-        want = min(want, max_entries)
-    if max_records is not None:
-        want = min(want, max_records)
-    piece = max(SPLIT_MIN_KEY_TILES, -(-total // want))
-    counts = [max(1, kt // piece) for kt in kts]
-    if max(counts) == 1:
+    if max(kts) < 2 * SPLIT_MIN_KEY_TILES:
         return None
-    # never more entries / records than the caller's fixed-size buffers hold
-    while ((max_entries is not None and sum(counts) > max_entries)
-           or (max_records is not None and sum(c for c in counts if c > 1) > max_records)):
-        i = max(range(len(counts)), key=lambda j: counts[j])
-        counts[i] -= 1
+    whole = _whole_cost(kts, head_groups)
+    ideal = (sum(kts) + SPLIT_WG_OVERHEAD * len(kts)) * head_groups / TILE_CUS
+    if whole < 1.1 * ideal + SPLIT_MERGE_COST:  # balanced as it is
+        return None
+    lengths = {}
+    for kt in kts:
+        lengths[kt] = lengths.get(kt, 0) + 1
+    per_round = max(1, TILE_CUS // head_groups)  # work-list entries that fill the chip once
+    first = -(-len(seqs) // per_round)
+    best, best_cost = None, 0.95 * whole  # a cut has to pay for itself
+    for rounds in range(first, first + (SPLIT_CANDIDATES if len(lengths) <= 16 else 3)):
+        budget = rounds * per_round
+        if max_entries is not None:
+            budget = min(budget, max_entries)
+        if max_records is not None:  # every entry may end up with a record of its own
+            budget = min(budget, max_records)
+        counts = _split_counts(lengths, budget)
+        if counts is None or max(counts.values()) == 1:
+            continue
+        n = sum(m * counts[kt] for kt, m in lengths.items())
+        records = sum(m * counts[kt] for kt, m in lengths.items() if counts[kt] > 1)
+        longest = max(-(-kt // c) for kt, c in counts.items())
+        cost = (-(-n * head_groups // TILE_CUS) * (longest + SPLIT_WG_OVERHEAD)
+                + SPLIT_MERGE_COST + SPLIT_RECORD_COST * records * head_groups / 8)
+        if cost < best_cost:
+            best, best_cost = counts, cost
+    if best is None:
+        return None
+    best = [best[kt] for kt in kts]
     seqs2, q0s2, split, groups = [], [], [], []
     rec = 0
-    for s, q0, kt, c in zip(seqs, q0s, kts, counts):
+    for s, q0, kt, c in zip(seqs, q0s, kts, best):
         if c == 1:
             seqs2.append(s)
             q0s2.append(q0)
