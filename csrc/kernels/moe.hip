@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t* __rest
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < topk; ++k) {
       const float w = weights[(long)t * topk + k];
+      if (w == 0.f) continue;  // a pair of an expert held by another rank: its row was never written
       const long row = pos[(long)t * topk + k];
       const u32x4 a = *reinterpret_cast<const u32x4*>(y + row * hidden + i);
 #pragma unroll

@@ -1049,6 +1049,42 @@ def test_moe_prefill_grouped_gemm_experts(t, hidden, inter, skew):
     assert err < 8e-3, err
 
 
+@pytest.mark.parametrize("t,hidden,inter,ranks,skew", [
+    (3, 512, 1024, 2, False), (40, 512, 1024, 4, False), (40, 512, 1024, 2, True),
+    (300, 512, 1024, 2, False), (1024, 512, 1024, 4, True), (2048, 4096, 14336, 2, False)])
+def test_moe_expert_parallel_ranks_sum_to_the_whole_layer(t, hidden, inter, ranks, skew):
+    """Expert parallelism: every rank holds a range of whole experts and runs only the pairs routed
+    there (the others sort into a bucket no kernel visits and carry weight 0).  The ranks' outputs,
+    summed as the layer's all-reduce would, must be the whole layer's fp32 definition.  `skew`
+    routes every token to experts 3 and 6, so some ranks have no pair at all."""
+    torch.manual_seed(29)
+    e, k = 8, 2
+    x = torch.randn(t, hidden, device=DEV).to(BF)
+    w13 = (torch.randn(e, 2 * inter, hidden, device=DEV) * 0.03).to(BF)
+    w2 = (torch.randn(e, hidden, inter, device=DEV) * 0.03).to(BF)
+    logits = torch.randn(t, e, device=DEV).to(BF)
+    if skew:
+        logits[:, 3] += 20.0
+        logits[:, 6] += 10.0
+    w, ids = ops.moe_topk_softmax(logits, k)
+    exp = _moe_fp32_definition(x, w13, w2, ids, w, inter)
+    per = e // ranks
+    total = torch.zeros_like(exp)
+    for r in range(ranks):
+        lids, lw = ops.moe_localize(ids, w, r * per, per, bucket=True)
+        assert int(lids.max()) <= per and bool(((lids == per) == (lw == 0)).all())
+        mine = w13[r * per:(r + 1) * per].contiguous(), w2[r * per:(r + 1) * per].contiguous()
+        # poison what the allocator hands out next: rows of foreign pairs are never written and must not be read
+        junk = torch.full((t * k, max(hidden, inter)), float("nan"), device=DEV, dtype=BF)
+        del junk
+        fn = ops.moe_experts_grouped if t <= ops.MOE_MFMA_MAX_TOKENS else ops.moe_experts_prefill
+        out = fn(x, mine[0], mine[1], lids, lw, foreign=True).float()
+        assert torch.isfinite(out).all()
+        total += out
+    err = (total - exp).abs().max().item() / exp.abs().max().item()
+    assert err < 8e-3, err
+
+
 @pytest.mark.parametrize("t,in_dim,outs,r_pad", [
     (1, 4096, [4096, 1024, 1024], 32), (37, 512, [256], 32), (300, 1024, [512, 512], 64),
     (40, 14336, [4096], 32)])

@@ -33,7 +33,7 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _rank_main(rank, world, port, model, tp, pp, q):
+def _rank_main(rank, world, port, model, tp, pp, q, ep=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
@@ -42,7 +42,8 @@ def _rank_main(rank, world, port, model, tp, pp, q):
     from vllm_production_stack_amd.parallel.state import get_replica
 
     init_parallel_from_env(tp, pp)
-    eng = LLMEngine(_cfg(model, tensor_parallel_size=tp, pipeline_parallel_size=pp))
+    eng = LLMEngine(_cfg(model, tensor_parallel_size=tp, pipeline_parallel_size=pp, enable_expert_parallel=ep))
+    assert eng.runner.model.ep == ep
     if get_replica().is_driver:
         outs = eng.generate(_prompts(), copy.deepcopy(SP))
         # a second wave through the prefix cache and a chunked prefill (budget 128 < 150 rows)
@@ -58,12 +59,12 @@ def _rank_main(rank, world, port, model, tp, pp, q):
     dist.destroy_process_group()
 
 
-def _run_layout(model, tp, pp):
+def _run_layout(model, tp, pp, ep=False):
     world = tp * pp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, model, tp, pp, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, model, tp, pp, q, ep)) for r in range(world)]
     for p in procs:
         p.start()
     import queue as _queue
@@ -107,6 +108,16 @@ def _single(model):
 def test_parallel_layout_matches_single_process(model, tp, pp):
     want = _single(model)
     got = _run_layout(model, tp, pp)
+    assert got[0] == want[0]
+    assert got[1] == want[1]
+
+
+def test_expert_parallel_ranks_hold_whole_experts_and_match_single_process():
+    """``--enable-expert-parallel``: the two ranks of a tensor-parallel Mixtral hold four whole
+    experts each; pairs routed to the other rank's experts contribute nothing locally and the
+    layer's all-reduce sums the halves."""
+    want = _single("tiny-mixtral")
+    got = _run_layout("tiny-mixtral", 2, 1, ep=True)
     assert got[0] == want[0]
     assert got[1] == want[1]
 

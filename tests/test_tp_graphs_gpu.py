@@ -34,7 +34,7 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _rank_main(rank, world, port, eager, q):
+def _rank_main(rank, world, port, eager, q, model="tiny-llama-gqa", ep=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VPSA_TP_BACKEND="gloo",
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -45,11 +45,11 @@ def _rank_main(rank, world, port, eager, q):
     from vllm_production_stack_amd.parallel.state import get_replica, get_tp
 
     init_parallel_from_env(world, 1)
-    cfg = EngineConfig(model="tiny-llama-gqa", max_model_len=1024, max_num_seqs=8,
+    cfg = EngineConfig(model=model, max_model_len=1024, max_num_seqs=8,
                        max_num_batched_tokens=256, num_gpu_blocks_override=96, port=0,
-                       tensor_parallel_size=world, enforce_eager=eager)
+                       tensor_parallel_size=world, enforce_eager=eager, enable_expert_parallel=ep)
     eng = LLMEngine(cfg)
-    info = {"rank": rank, "graphs": len(eng.runner._graphs), "use_graphs": eng.runner.use_graphs,
+    info = {"rank": rank, "experts": list(eng.runner.model.layers[0].w13.shape) if ep else None, "graphs": len(eng.runner._graphs), "use_graphs": eng.runner.use_graphs,
             "oneshot": get_tp().oneshot is not None}
     if get_replica().is_driver:
         outs = eng.generate(_prompts(), copy.deepcopy(SP))
@@ -66,12 +66,12 @@ def _rank_main(rank, world, port, eager, q):
     dist.destroy_process_group()
 
 
-def _run(eager: bool):
+def _run(eager: bool, model="tiny-llama-gqa", ep=False):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, eager, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, eager, q, model, ep)) for r in range(world)]
     for p in procs:
         p.start()
     import queue as _queue
@@ -107,6 +107,23 @@ def test_tp2_graph_decode_matches_eager_and_runs_on_every_rank():
     assert d_graph[2] == d_eager[2], (d_graph[2], d_eager[2])
     assert d_graph[3] == d_eager[3]
     assert all(len(o) == SP.max_tokens for o in d_graph[2])
+
+
+def test_expert_parallel_replica_replays_graphs_and_agrees_with_sliced_experts():
+    """``--enable-expert-parallel`` on two ranks: each holds two whole experts of four (full width),
+    decode steps replay graphs whose MoE layers sort foreign pairs out of the way, and the tokens
+    are those of the eager run; against the layout that slices every expert the two differ only by
+    the order of bf16 sums, so the first tokens agree."""
+    d_eager, _ = _run(eager=True, model="tiny-mixtral-wide", ep=True)
+    d_graph, w_graph = _run(eager=False, model="tiny-mixtral-wide", ep=True)
+    for info in (d_graph[1], w_graph[1]):
+        assert info["experts"] == [2, 2048, 256], info
+        assert info["use_graphs"] and info["graphs"] > 0 and not info["failed"], info
+    assert d_graph[2] == d_eager[2], (d_graph[2], d_eager[2])
+    assert d_graph[3] == d_eager[3]
+    d_sliced, _ = _run(eager=True, model="tiny-mixtral-wide", ep=False)
+    same_first = sum(a[0] == b[0] for a, b in zip(d_eager[2], d_sliced[2]))
+    assert same_first >= len(d_eager[2]) - 1, (d_eager[2], d_sliced[2])
 
 
 def test_pipeline_stages_on_the_hip_kernels_hand_over_through_the_host():

@@ -42,6 +42,9 @@ def build_parser() -> argparse.ArgumentParser:
     s.add_argument("--num-gpu-blocks-override", type=int, default=None)
     s.add_argument("--tensor-parallel-size", "--tensor_parallel_size", "-tp", type=int, default=1)
     s.add_argument("--pipeline-parallel-size", "--pipeline_parallel_size", "-pp", type=int, default=1)
+    s.add_argument("--enable-expert-parallel", "--enable_expert_parallel", action="store_true",
+                   help="mixture-of-experts layers: every tensor-parallel rank holds whole experts "
+                        "instead of a slice of each")
     s.add_argument("--distributed-executor-backend", default=None)
     _bool_pair(s, "enable-prefix-caching", True, "hash-chained prefix cache over KV pages")
     _bool_pair(s, "enable-chunked-prefill", True, "split long prompts across steps")
@@ -81,6 +84,7 @@ def config_from_args(args: argparse.Namespace) -> EngineConfig:
         enable_chunked_prefill=args.enable_chunked_prefill,
         tensor_parallel_size=args.tensor_parallel_size,
         pipeline_parallel_size=args.pipeline_parallel_size,
+        enable_expert_parallel=args.enable_expert_parallel,
         distributed_executor_backend=args.distributed_executor_backend,
         enable_lora=args.enable_lora, max_loras=args.max_loras, max_lora_rank=args.max_lora_rank,
         enable_sleep_mode=args.enable_sleep_mode,

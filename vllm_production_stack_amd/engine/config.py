@@ -136,6 +136,10 @@ PRESETS: dict[str, ModelConfig] = {
     "tiny-mixtral": ModelConfig(name="tiny-mixtral", architecture="mixtral", num_heads=4,
                                 num_kv_heads=2, hidden_size=256, intermediate_size=256,
                                 num_experts=4, num_experts_per_tok=2),
+    # expert widths the matrix-core decode kernels tile (whole and halved)
+    "tiny-mixtral-wide": ModelConfig(name="tiny-mixtral-wide", architecture="mixtral", num_heads=4,
+                                     num_kv_heads=2, hidden_size=256, intermediate_size=1024,
+                                     num_experts=4, num_experts_per_tok=2),
     # heads of 64 channels (the geometry of OPT-125m, GPT-2, Llama-3.2-1B, Qwen2-0.5B)
     "tiny-opt-hd64": ModelConfig(name="tiny-opt-hd64", architecture="opt", vocab_size=512, hidden_size=256,
                                  intermediate_size=512, ffn_dim=512, num_layers=2, num_heads=4,
@@ -354,6 +358,7 @@ class EngineConfig:
     enable_chunked_prefill: bool = True
     tensor_parallel_size: int = 1
     pipeline_parallel_size: int = 1
+    enable_expert_parallel: bool = False  # MoE layers: whole experts per tensor-parallel rank
     distributed_executor_backend: str | None = None
     enable_lora: bool = False
     max_loras: int = 1

@@ -58,7 +58,7 @@ class ModelRunner:
             ops.bind_device(device.index if device.index is not None else torch.cuda.current_device())
         t0 = time.time()
         self.model = build_model(model_cfg, self.dtype, device, self.max_model_len, ckpt_dir,
-                                 cfg.seed, cfg.load_format)
+                                 cfg.seed, cfg.load_format, expert_parallel=cfg.enable_expert_parallel)
         log.info("model %s ready: %.2f GiB weights in %.1fs", model_cfg.name,
                  self.model.weight_bytes() / 2**30, time.time() - t0)
         self._pack_decode_weights()

@@ -20,9 +20,12 @@ from .transformer import LayerWeights, TransformerModel
 
 
 def build_model(cfg: ModelConfig, dtype: torch.dtype, device: torch.device, max_model_len: int,
-                ckpt_dir: Path | None = None, seed: int = 0, load_format: str = "auto"):
-    cls = OPTModel if cfg.architecture in ("opt", "gpt2") else TransformerModel
-    model = cls(cfg, dtype, device, max_model_len)
+                ckpt_dir: Path | None = None, seed: int = 0, load_format: str = "auto",
+                expert_parallel: bool = False):
+    if cfg.architecture in ("opt", "gpt2"):
+        model = OPTModel(cfg, dtype, device, max_model_len)
+    else:
+        model = TransformerModel(cfg, dtype, device, max_model_len, expert_parallel=expert_parallel)
     has_weights = ckpt_dir is not None and any(Path(ckpt_dir).glob("*.safetensors"))
     if has_weights and load_format != "dummy":
         model.init_random(seed)  # allocates every tensor; checkpoint values overwrite them
@@ -127,7 +130,17 @@ def _load_llama(model: TransformerModel, ckpt_dir: Path) -> None:
             me = re.match(r"block_sparse_moe\.experts\.(\d+)\.(w[123])\.weight", sub)
             if me:
                 ex, which = int(me.group(1)), me.group(2)
-                if which == "w1":
+                if model.ep:  # whole experts, this rank's range of them
+                    ex -= model.first_expert
+                    if 0 <= ex < model.local_experts:
+                        full = cfg.intermediate_size
+                        if which == "w1":
+                            lw.w13[ex, :full].copy_(t)
+                        elif which == "w3":
+                            lw.w13[ex, full:].copy_(t)
+                        else:
+                            lw.w2[ex].copy_(t)
+                elif which == "w1":
                     lw.w13[ex, :inter].copy_(_shard_rows(t, r, s))
                 elif which == "w3":
                     lw.w13[ex, inter:].copy_(_shard_rows(t, r, s))

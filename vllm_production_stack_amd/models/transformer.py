@@ -37,7 +37,7 @@ class LayerWeights:
 
 class TransformerModel:
     def __init__(self, cfg: ModelConfig, dtype: torch.dtype, device: torch.device,
-                 max_model_len: int):
+                 max_model_len: int, expert_parallel: bool = False):
         self.cfg = cfg
         self.dtype = dtype
         self.device = device
@@ -50,6 +50,16 @@ class TransformerModel:
         self.n_kv = cfg.num_kv_heads // tp.size
         self.head_dim = cfg.head_dim
         self.inter = cfg.intermediate_size // tp.size
+        # Expert parallelism inside the tensor-parallel group: a rank holds whole experts (a
+        # contiguous range of them) instead of a slice of every expert.  Attention stays tensor
+        # parallel, so every rank sees every token; it runs the pairs routed to its own experts and
+        # the all-reduce that closes the layer sums the ranks' contributions, as it does for slices.
+        self.ep = bool(expert_parallel) and tp.size > 1 and cfg.num_experts > 0
+        if self.ep:
+            assert cfg.num_experts % tp.size == 0, "expert parallelism needs the rank count to divide the experts"
+        self.local_experts = cfg.num_experts // tp.size if self.ep else cfg.num_experts
+        self.first_expert = tp.rank * self.local_experts if self.ep else 0
+        self.moe_inter = cfg.intermediate_size if self.ep else self.inter
         self.vocab_shard = (cfg.vocab_size + tp.size - 1) // tp.size
         self.scale = 1.0 / math.sqrt(cfg.head_dim)
         self.layers: list[LayerWeights] = []
@@ -109,12 +119,16 @@ class TransformerModel:
             if cfg.num_experts > 0:
                 lw.router = self._rand(seed, k + 4, cfg.num_experts, h)
                 w13, w2 = [], []
-                for ex in range(cfg.num_experts):
+                for ex in range(self.first_expert, self.first_expert + self.local_experts):
                     g_ = self._rand(seed, k + 8 + 3 * ex, cfg.intermediate_size, h)
                     u_ = self._rand(seed, k + 9 + 3 * ex, cfg.intermediate_size, h)
                     d_ = self._rand(seed, k + 10 + 3 * ex, h, cfg.intermediate_size)
-                    w13.append(torch.cat([rows(g_, inter), rows(u_, inter)]))
-                    w2.append(d_[:, r * inter:(r + 1) * inter])
+                    if self.ep:
+                        w13.append(torch.cat([g_, u_]))
+                        w2.append(d_)
+                    else:
+                        w13.append(torch.cat([rows(g_, inter), rows(u_, inter)]))
+                        w2.append(d_[:, r * inter:(r + 1) * inter])
                     del g_, u_, d_
                 lw.w13 = torch.stack(w13).contiguous()
                 lw.w2 = torch.stack(w2).contiguous()
@@ -196,34 +210,43 @@ class TransformerModel:
     def _moe(self, x: torch.Tensor, lw: LayerWeights, decode_only: bool) -> torch.Tensor:
         cfg = self.cfg
         t = x.shape[0]
-        e, k = cfg.num_experts, cfg.num_experts_per_tok
+        e, k = self.local_experts, cfg.num_experts_per_tok
         logits = F.linear(x, lw.router)
         w, ids = ops.moe_topk_softmax(logits, k)
-        if decode_only and t <= 2 and x.is_cuda:
+        mfma = x.is_cuda and t <= ops.MOE_MFMA_MAX_TOKENS and ops.moe_mfma_supported(x.shape[1], lw.w2.shape[2])
+        tiled = (x.is_cuda and not (decode_only or t <= 16)
+                 and ops.grouped_gemm_supported(2 * lw.w2.shape[2], x.shape[1], True)
+                 and ops.grouped_gemm_supported(x.shape[1], lw.w2.shape[2]))
+        ep = self.ep
+        if ep:
+            # pairs routed to another rank's experts: the sorting kernels put them in a bucket past
+            # the last local expert that no GEMM visits; everywhere else they run on expert 0 with
+            # weight 0 (correct, and only taken on the CPU and on shapes the kernels do not tile)
+            ids, w = ops.moe_localize(ids, w, self.first_expert, e, bucket=mfma or tiled)
+        if decode_only and t <= 2 and x.is_cuda and not ep:
             # one or two tokens rarely share an expert: per-pair GEMV kernels, no sort
             return ops.moe_experts_small_batch(x, lw.w13, lw.w2, ids, w)
-        if x.is_cuda and t <= ops.MOE_MFMA_MAX_TOKENS and ops.moe_mfma_supported(x.shape[1], lw.w2.shape[2]):
+        if mfma:
             # Decode-sized batches: sort the (token, expert) pairs by expert and stream each
             # routed expert's weights once against all of its tokens (matrix-core kernels,
             # no host sync: HIP-graph capturable).
-            return ops.moe_experts_grouped(x, lw.w13, lw.w2, ids, w)
+            return ops.moe_experts_grouped(x, lw.w13, lw.w2, ids, w, foreign=ep)
         if decode_only and t <= 16 and x.is_cuda:
             return ops.moe_experts_small_batch(x, lw.w13, lw.w2, ids, w)
         if decode_only or t <= 16:
             # Small batches on odd shapes / the CPU: run all experts on all rows (no host
             # sync) and mix with the routing matrix.
             dense = torch.zeros((t, e), dtype=torch.float32, device=x.device)
-            dense.scatter_(1, ids.long(), w)
+            dense.scatter_add_(1, ids.long(), w)
             gu = torch.matmul(x.unsqueeze(0), lw.w13.transpose(1, 2))  # [E, T, 2I]
             act = ops.silu_and_mul(gu.view(e * t, -1)).view(e, t, -1)
             y = torch.matmul(act, lw.w2.transpose(1, 2))  # [E, T, H]
             return (y.float() * dense.t().unsqueeze(-1)).sum(0).to(x.dtype)
-        if (x.is_cuda and ops.grouped_gemm_supported(2 * lw.w2.shape[2], x.shape[1], True)
-                and ops.grouped_gemm_supported(x.shape[1], lw.w2.shape[2])):
+        if tiled:
             # Prefill chunks of any size: two grouped matrix-core GEMMs over the device-sorted
             # (token, expert) pairs (gate_up gathers its rows and fuses SwiGLU).  The host never reads
             # the per-expert counts, so it keeps launching ahead of the GPU.
-            return ops.moe_experts_prefill(x, lw.w13, lw.w2, ids, w)
+            return ops.moe_experts_prefill(x, lw.w13, lw.w2, ids, w, foreign=ep)
         # The CPU, and shapes the grouped kernel does not tile: per-expert products on the sorted rows
         offsets, pos, sorted_tok = ops.moe_align(ids, e)
         xs = ops.moe_permute(x, sorted_tok)

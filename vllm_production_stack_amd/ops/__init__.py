@@ -954,6 +954,17 @@ def moe_topk_softmax(logits, topk, renorm=True):
     return w, ids
 
 
+def moe_localize(ids, weights, first, count, bucket):
+    """Routing of a rank that holds experts ``first .. first + count`` only: ids become local, and a
+    pair routed elsewhere gets weight 0 and the id ``count`` (``bucket``: a sorting bucket of its
+    own that ``moe_experts_grouped`` / ``moe_experts_prefill`` skip with ``foreign=True``) or 0."""
+    local = ids - first
+    here = (local >= 0) & (local < count)
+    elsewhere = count if bucket else 0
+    return (torch.where(here, local, elsewhere).to(torch.int32),
+            torch.where(here, weights, 0.0).to(weights.dtype))
+
+
 def moe_align(ids, n_experts):
     """ids [T, K] int32 -> (offsets [E+1], pos [T*K], sorted_tok [T*K])."""
     t, k = ids.shape
@@ -1010,8 +1021,10 @@ def moe_mfma_supported(hidden: int, inter: int) -> bool:
     return hidden % 128 == 0 and inter % 512 == 0
 
 
-def moe_experts_grouped(x, w13, w2, ids, weights):
+def moe_experts_grouped(x, w13, w2, ids, weights, foreign=False):
     """Expert MLP for a decode-sized batch: out[t] = sum_k weights[t,k] * MLP_{ids[t,k]}(x[t]).
+    ``foreign``: ids may equal the expert count (a pair of an expert held by another rank, weight
+    0): those pairs sort behind the last expert and no kernel touches them.
 
     Same contract as ``moe_experts_small_batch``; here the (token, k) pairs are sorted by expert
     first, and each expert's weights are streamed once against all of its tokens on the matrix
@@ -1025,7 +1038,7 @@ def moe_experts_grouped(x, w13, w2, ids, weights):
     assert w13.shape[1] == 2 * inter and w13.shape[2] == hidden and w2.shape[1] == hidden
     assert w13.is_contiguous() and w2.is_contiguous() and ids.dtype == torch.int32
     assert moe_mfma_supported(hidden, inter), (hidden, inter)
-    offsets, pos, sorted_tok = moe_align(ids, n_experts)
+    offsets, pos, sorted_tok = moe_align(ids, n_experts + (1 if foreign else 0))
     act = torch.empty((t * k, inter), dtype=x.dtype, device=x.device)
     y = torch.empty((t * k, hidden), dtype=x.dtype, device=x.device)
     rc = _kernels().vpsa_moe_mfma(_p(x.contiguous()), _p(w13), _p(w2), _p(offsets), _p(sorted_tok),
@@ -1118,7 +1131,7 @@ def grouped_gemm_supported(n: int, k: int, silu_mul: bool = False) -> bool:
     return k % 64 == 0 and (not silu_mul or (n // 2) % 32 == 0)
 
 
-def moe_experts_prefill(x, w13, w2, ids, weights, gather=True):
+def moe_experts_prefill(x, w13, w2, ids, weights, gather=True, foreign=False):
     """Expert MLP for prefill-sized batches: the (token, k) pairs are sorted by expert on the device
     and two grouped matrix-core GEMMs run over all experts at once: gate_up gathers its token
     rows by index and fuses silu(gate) * up, down writes the sorted rows that the weighted combine
@@ -1127,7 +1140,9 @@ def moe_experts_prefill(x, w13, w2, ids, weights, gather=True):
     if not x.is_cuda:
         return reference.moe_experts(x, w13, w2, ids, weights)
     n_experts = w13.shape[0]
-    offsets, pos, sorted_tok = moe_align(ids, n_experts)
+    offsets, pos, sorted_tok = moe_align(ids, n_experts + (1 if foreign else 0))
+    if foreign:  # the bucket of pairs held elsewhere ends the list: the GEMMs stop at offsets[n_experts]
+        offsets = offsets[: n_experts + 1]
     gg = tile_gemm if (tile_gemm_supported(w13.shape[1], w13.shape[2], True)
                        and tile_gemm_supported(w2.shape[1], w2.shape[2])) else grouped_gemm
     if gather:
