@@ -37,6 +37,23 @@ def wait_http(url: str, timeout: float) -> None:
     raise RuntimeError(f"{url} did not come up in {timeout}s")
 
 
+def engine_latency_sums(url: str) -> dict:
+    """Sum and count of the engine's own latency histograms (arrival at the engine to first token,
+    time in its waiting queue): what a replica saw, to set against what the client saw."""
+    out = {}
+    try:
+        with urllib.request.urlopen(url + "/metrics", timeout=5) as r:  # noqa: S310
+            for line in r.read().decode().splitlines():
+                for key, name in (("ttft", "vllm:time_to_first_token_seconds"),
+                                  ("queue", "vllm:request_queue_time_seconds")):
+                    for part in ("sum", "count"):
+                        if line.startswith(f"{name}_{part}"):
+                            out[f"{key}_{part}"] = out.get(f"{key}_{part}", 0.0) + float(line.rsplit(" ", 1)[1])
+    except Exception:  # noqa: BLE001
+        pass
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -52,6 +69,8 @@ def main():
     ap.add_argument("--cpu-offload-gb", type=float, default=0.0)
     ap.add_argument("--no-prefix-caching", action="store_true",
                     help="the 'naive' arm of the A/B: every turn recomputes its whole history")
+    ap.add_argument("--no-chunked-prefill", action="store_true",
+                    help="whole prompts in one step (the reference's benchmark configuration)")
     ap.add_argument("--base-port", type=int, default=18300)
     ap.add_argument("--out", default="sweep.jsonl")
     ap.add_argument("--device", default="cuda")
@@ -68,8 +87,10 @@ def main():
                 e.update(LMCACHE_LOCAL_CPU="True", LMCACHE_MAX_LOCAL_CPU_SIZE=str(a.cpu_offload_gb))
             cmd = [sys.executable, "-m", "vllm_production_stack_amd.engine.cli", "serve", a.model,
                    "--host", "127.0.0.1", "--port", str(a.base_port + 1 + g), "--max-model-len", "32000",
-                   "--max-num-batched-tokens", "8192", "--disable-log-requests", "--log-level", "warning",
-                   "--no-enable-prefix-caching" if a.no_prefix_caching else "--enable-prefix-caching"]
+                   "--max-num-batched-tokens", "32000" if a.no_chunked_prefill else "8192",
+                   "--disable-log-requests", "--log-level", "warning",
+                   "--no-enable-prefix-caching" if a.no_prefix_caching else "--enable-prefix-caching",
+                   "--no-enable-chunked-prefill" if a.no_chunked_prefill else "--enable-chunked-prefill"]
             if a.device != "cuda":
                 cmd += ["--device", "cpu", "--dtype", "float32"]
             procs.append(subprocess.Popen(cmd, env=e, cwd=ROOT))
@@ -94,15 +115,23 @@ def main():
                     "--init-user-id", str(uid), "--request-with-user-id", "--log-interval", "1000000",
                     "--output", os.devnull])
                 t0 = time.time()
+                before = engine_latency_sums(f"http://127.0.0.1:{a.base_port + 1}")
                 sessions = asyncio.run(mrq.run_open_loop(args))
+                after = engine_latency_sums(f"http://127.0.0.1:{a.base_port + 1}")
                 uid += len(sessions) + 1
                 rows = mrq.rows_of(sessions)
                 s = mrq.summarize(rows, t0, time.time(), 0, q, out=io.StringIO())
                 rec = {"qps": q, "gpus": a.gpus, "num_users": a.num_users, "num_rounds": a.num_rounds,
                        "history_tokens": a.user_history_prompt, "system_tokens": a.shared_system_prompt,
                        "answer_len": a.answer_len, "seconds": a.time, "routing": a.routing_logic,
-                       "prefix_caching": not a.no_prefix_caching, "cpu_offload_gb": a.cpu_offload_gb,
+                       "prefix_caching": not a.no_prefix_caching, "chunked_prefill": not a.no_chunked_prefill,
+                       "cpu_offload_gb": a.cpu_offload_gb,
                        **{k: round(v, 4) if isinstance(v, float) else v for k, v in s.items()}}
+                n_eng = after.get("ttft_count", 0) - before.get("ttft_count", 0)
+                if n_eng > 0:  # replica 0's own view (includes the client's ten warm-up prompts)
+                    rec["engine0_mean_ttft_s"] = round((after["ttft_sum"] - before["ttft_sum"]) / n_eng, 4)
+                    rec["engine0_mean_queue_s"] = round(
+                        (after.get("queue_sum", 0) - before.get("queue_sum", 0)) / n_eng, 4)
                 print(json.dumps(rec), flush=True)
                 out.write(json.dumps(rec) + "\n")
                 out.flush()

@@ -22,9 +22,23 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="llama-3-8b")
     ap.add_argument("--n", type=int, default=5)
+    ap.add_argument("--gaps", default="0,3", help="idle seconds in front of every prompt, one series per value")
+    ap.add_argument("--no-chunked-prefill", action="store_true", help="whole prompts in one step")
+    ap.add_argument("--no-prefix-caching", action="store_true")
+    ap.add_argument("--cpu-offload-gb", type=float, default=0.0)
+    ap.add_argument("--engine-only", action="store_true", help="skip the HTTP half")
+    ap.add_argument("--mrq-style", action="store_true",
+                    help="HTTP half: the benchmark client's own prompts (new users, then a follow-up turn "
+                         "each, 100 answer tokens), with the engine's time split per request")
     a = ap.parse_args()
+    from vllm_production_stack_amd.engine.config import KVOffloadConfig
+
     eng = LLMEngine(EngineConfig(model=a.model, max_model_len=32000, max_num_seqs=256,
-                                 max_num_batched_tokens=8192, enable_prefix_caching=True))
+                                 max_num_batched_tokens=32000 if a.no_chunked_prefill else 8192,
+                                 enable_chunked_prefill=not a.no_chunked_prefill,
+                                 enable_prefix_caching=not a.no_prefix_caching,
+                                 kv_offload=KVOffloadConfig(local_cpu=a.cpu_offload_gb > 0,
+                                                            max_local_cpu_gb=a.cpu_offload_gb)))
     g = torch.Generator().manual_seed(0)
     sp = SamplingParams(max_tokens=1, temperature=0, ignore_eos=True)
 
@@ -44,8 +58,10 @@ def main():
         return round(time.perf_counter() - t0, 4), steps
 
     eng.generate([prompt(300)], copy.deepcopy(sp))
-    for gap, lens in ((0.0, [21000] * a.n), (0.0, [21000 + 137 * i for i in range(a.n)]),
-                      (3.0, [21000] * a.n), (3.0, [21500 + 91 * i for i in range(a.n)])):
+    series = []
+    for k, gap in enumerate(float(v) for v in a.gaps.split(",")):
+        series += [(gap, [21000] * a.n), (gap, [21000 + 500 * k + 137 * i for i in range(a.n)])]
+    for gap, lens in series:
         out = []
         for n in lens:
             if gap:
@@ -54,6 +70,11 @@ def main():
         print(json.dumps({"case": "engine_only", "idle_gap_s": gap, "lens": lens,
                           "seconds": [o[0] for o in out], "step_ms": [o[1] for o in out]}), flush=True)
 
+    if a.engine_only:
+        print(json.dumps({"case": "prof", **{k: round(v, 3) if isinstance(v, float) else v
+                                             for k, v in eng.prof.items()}}), flush=True)
+        eng.shutdown()
+        return
     # through the engine's HTTP server, directly and behind the router
     import subprocess
 
@@ -83,6 +104,39 @@ def main():
                                 first = time.perf_counter() - t0
                                 break
         return {"ttft": round(first or -1, 4), "total": round(time.perf_counter() - t0, 4)}
+
+    async def mrq_part():
+        sys.path.insert(0, os.path.join(root, "benchmarks", "multi_round_qa"))
+        import multi_round_qa as mrq
+
+        ae = AsyncLLMEngine(eng)
+        ae.start(asyncio.get_running_loop())
+        runner = await serve(ae, "127.0.0.1", 18700)
+        ex = mrq.RequestExecutor("http://127.0.0.1:18700", "EMPTY", a.model)
+        await ex.start()
+        cfg = mrq.WorkloadConfig(4, 1000, 20000, 100, 20, 1.0, a.model, True)
+        users = [mrq.UserSession(900 + i, cfg) for i in range(a.n)]
+        rows = []
+        try:
+            for turn in range(2):
+                for u in users:
+                    await asyncio.sleep(2.0)
+                    before = dict(eng.prof)
+                    r = await ex.chat(u.next_messages(), 100, u.headers())
+                    u.on_answer(r)
+                    d = {k: round(eng.prof[k] - before[k], 3) for k in ("t_schedule", "t_execute", "t_post")}
+                    rows.append({"turn": turn + 1, "client_ttft": round(r.ttft, 4), "prompt_tokens": r.prompt_tokens,
+                                 "steps": eng.prof["steps"] - before["steps"], **d})
+        finally:
+            await ex.close()
+            await runner.cleanup()
+            ae.stop()
+        return rows
+
+    if a.mrq_style:
+        for row in asyncio.run(mrq_part()):
+            print(json.dumps({"case": "http_mrq", **row}), flush=True)
+        return
 
     async def http_part():
         ae = AsyncLLMEngine(eng)

@@ -380,6 +380,61 @@ def test_prefix_caching_off_with_host_tier_serves_every_turn_from_host():
     eng.shutdown()
 
 
+@pytest.mark.parametrize("prefix_caching", [False, True])
+def test_pages_filled_by_a_requests_last_token_are_offloaded_while_still_owned(prefix_caching):
+    """A request whose last computed token fills a page finishes in the step that fills it.  The
+    offload copy takes a reference on that page, which is only worth something while the request
+    still owns the page: taken after the request had handed the page back, it landed on a free
+    page, the next request was given that page with a fresh count of one, and the copy's release
+    freed it under the new owner (two requests writing one page; later a negative count)."""
+    cfg = EngineConfig(model="tiny-llama", device="cpu", dtype="float32", max_model_len=1024,
+                       max_num_seqs=8, max_num_batched_tokens=256, num_gpu_blocks_override=24,
+                       enable_prefix_caching=prefix_caching,
+                       kv_offload=KVOffloadConfig(local_cpu=True, max_local_cpu_gb=0.05), port=0)
+    eng = LLMEngine(cfg)
+    seen = []
+    orig = eng.connector.store_pages
+
+    def spy(fresh):
+        seen.append([eng.bm.ref[p] for _, p in fresh])
+        eng.bm.pin([p for _, p in fresh])  # what an asynchronous copy does ...
+        eng.bm.free([p for _, p in fresh])  # ... and what its completion does
+        return orig(fresh)
+
+    eng.connector.store_pages = spy
+    sp = SamplingParams(max_tokens=5, temperature=0, ignore_eos=True)
+    # 60 prompt tokens + 4 computed output tokens = 64: the page fills in the step that samples the 5th
+    for seed in (31, 32, 33):
+        eng.generate(prompts(1, 60, seed=seed), copy.deepcopy(sp))
+    assert len(seen) == 3 and all(r and min(r) > 0 for r in seen), seen
+    assert eng.bm.num_free() == 24 and all(c == 0 for c in eng.bm.ref)
+    assert len(set(eng.bm.free_ids)) == len(eng.bm.free_ids)  # no page is on the free list twice
+    eng.shutdown()
+
+
+def test_a_free_page_cannot_be_pinned():
+    from vllm_production_stack_amd.engine.block_manager import BlockManager
+
+    bm = BlockManager(4)
+    (p,) = bm.allocate(1)
+    bm.pin([p])
+    bm.free([p])
+    assert bm.ref[p] == 1 and p not in bm.free_ids  # the reader's reference keeps it
+    bm.free([p])
+    assert p in bm.free_ids
+    with pytest.raises(AssertionError, match="is free"):
+        bm.pin([p])
+    # a cached page waiting for eviction can be pinned and leaves the eviction list for that time
+    (q,) = bm.allocate(1)
+    bm.register(q, 1234)
+    bm.free([q])
+    assert q in bm.evictable
+    bm.pin([q])
+    assert q not in bm.evictable and bm.ref[q] == 1
+    bm.free([q])
+    assert q in bm.evictable
+
+
 def test_staged_download_returns_its_slots_when_the_connection_dies_half_way():
     """Bulk download of raw pages through the pinned staging ring: a cache server that stops
     answering after k pages must not cost the ring a single slot (a leaked slot per hiccup would

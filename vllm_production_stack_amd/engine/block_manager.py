@@ -112,6 +112,16 @@ class BlockManager:
             self.evictable.pop(p, None)
         self.ref[p] += 1
 
+    def pin(self, pages: Iterable[int]) -> None:
+        """One more reference on each page for an asynchronous reader (an offload copy, a push to
+        a decode replica); ``free`` gives it back.  Only pages somebody owns, or cached pages
+        waiting for eviction, can be pinned: a page on the free list may be handed out at any
+        moment, and a reference on it would be lost (``allocate`` starts a page at one)."""
+        for p in pages:
+            if self.ref[p] == 0 and p not in self.evictable:
+                raise AssertionError(f"page {p} is free: nothing to pin")
+            self._take(p)
+
     def register(self, page: int, h: int) -> None:
         """Mark ``page`` (now full) as holding the content identified by ``h``."""
         if not self.enable_prefix_caching or self.page_hash[page] is not None:

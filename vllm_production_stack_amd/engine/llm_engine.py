@@ -151,6 +151,7 @@ class LLMEngine:
         sampled = {id(s): (tok, info) for s, tok, info in results}
         outputs: list[StepOutput] = []
         fresh_pages: list[tuple[int, int]] = []
+        done: list[tuple[Request, str, float]] = []
         for s in out.decodes + out.prefills:
             req = s.req
             if s.start < req.prompt_len:
@@ -174,20 +175,26 @@ class LLMEngine:
             req.last_token = t
             reason = self._stop_reason(req, tok)
             if reason:
-                if self.connector is not None:
-                    # while the request still owns its pages (P->D push reads them)
-                    self.connector.on_request_finished(req)
-                self.scheduler.finish(req, reason)
-                self.requests.pop(req.request_id, None)
-                self.runner.sampler.forget(req.request_id)
-                self.metrics.e2e.observe(t - req.arrival)
-                self.metrics.success.inc()
+                done.append((req, reason, t))
             outputs.append(StepOutput(req.request_id, [tok], reason is not None, reason,
                                       req.prompt_len, len(req.output_ids), req.num_cached_tokens + req.num_external_tokens,
                                       (req.first_scheduled - req.arrival) if req.first_scheduled else 0.0,
                                       [info] if info is not None else None))
+        # Pages filled in this step go to the lower tiers BEFORE their requests finish: the copy
+        # takes a reference on each page, which only holds while somebody still owns it (a request
+        # whose last token fills a page would otherwise have handed that page back already, and the
+        # reference would land on a free page that the next request is given).
         if self.connector is not None and fresh_pages:
             self.connector.store_pages(fresh_pages)
+        for req, reason, t in done:
+            if self.connector is not None:
+                # while the request still owns its pages (P->D push reads them)
+                self.connector.on_request_finished(req)
+            self.scheduler.finish(req, reason)
+            self.requests.pop(req.request_id, None)
+            self.runner.sampler.forget(req.request_id)
+            self.metrics.e2e.observe(t - req.arrival)
+            self.metrics.success.inc()
         self.metrics.update_scheduler(self.scheduler, self.bm)
         del now
         pr = self.prof

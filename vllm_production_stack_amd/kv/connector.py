@@ -310,8 +310,7 @@ class KVConnector:
         ev = self.host.store(pairs)
         if ev is not None:
             pages = [p for _, p in pairs]
-            for p in pages:
-                self.engine.bm.ref[p] += 1
+            self.engine.bm.pin(pages)
             self._pending.append((ev, pages))
 
     def store_pages(self, fresh: list[tuple[int, int]]) -> None:
@@ -409,8 +408,7 @@ class KVConnector:
             ev = torch.cuda.Event()
             ev.record(st)
         pages = [p for _, p, _ in taken]
-        for p in pages:  # the HBM pages must stay put until the side-stream copy has read them
-            self.engine.bm.ref[p] += 1
+        self.engine.bm.pin(pages)  # the HBM pages must stay put until the side-stream copy has read them
         self._pending.append((_TorchEvent(ev), pages))
         for h, _, _ in taken:
             self.remote_known.add(h)

@@ -351,8 +351,7 @@ class PagePusher:
 
         pool = self.engine.runner.pool
         bm = self.engine.bm
-        for p in pages:  # the request may give its pages back before the copy has read them
-            bm.ref[p] += 1
+        bm.pin(pages)  # the request may give its pages back before the copy has read them
         ready = None
         if pool.is_cuda and pages:
             ready = torch.cuda.Event()
