@@ -23,6 +23,34 @@ from vllm_production_stack_amd.engine.llm_engine import LLMEngine
 from vllm_production_stack_amd.engine.request import SamplingParams
 
 N_SEEDS = 200
+
+
+class _LateEvent:
+    """Completion of a host-tier copy that reports done only after a few polls, as a copy queued
+    behind others on the GPU's copy stream does: the pages it reads stay pinned over several
+    steps, across the finish, preemption or abort of the request that owned them."""
+
+    def __init__(self, polls: int):
+        self.left = polls
+
+    def query(self) -> bool:
+        self.left -= 1
+        return self.left <= 0
+
+    def wait(self) -> None:
+        self.left = 0
+
+
+def _delay_host_copies(eng, rng: random.Random) -> None:
+    host = eng.connector.host
+    store = host.store
+
+    def late_store(items, compute_event=None):
+        fresh = [h for h, _ in items if h not in host.index]
+        store(items, compute_event)  # the CPU tier copies at once
+        return _LateEvent(rng.randint(1, 6)) if fresh else None
+
+    host.store = late_store
 _solo_engine = None
 _solo_cache: dict = {}
 
@@ -79,13 +107,16 @@ def test_random_interleavings_match_solo_generation(chunk):
             num_gpu_blocks_override=pages, enable_chunked_prefill=chunked, enable_prefix_caching=prefix,
             kv_offload=KVOffloadConfig(local_cpu=True, max_local_cpu_gb=0.004) if host else KVOffloadConfig(), port=0)
         eng = LLMEngine(cfg)
+        late = host and rng.random() < 0.7
+        if late:
+            _delay_host_copies(eng, rng)
         script = _script(rng)
         # a prompt that can never fit the pool (with its answer) would be refused: keep it feasible
         script = [(a, p[: (pages - 3) * 64 - 16], m, ab) for a, p, m, ab in script]
         live: dict[int, object] = {}
         aborted: set[int] = set()
         step = 0
-        tag = f"seed {seed} pages {pages} budget {budget} chunked {chunked} prefix {prefix} host {host}"
+        tag = f"seed {seed} pages {pages} budget {budget} chunked {chunked} prefix {prefix} host {host} late {late}"
         while step < 1500:
             for i, (arrive, prompt, max_tokens, _ab) in enumerate(script):
                 if arrive == step:
@@ -113,4 +144,6 @@ def test_random_interleavings_match_solo_generation(chunk):
         assert not any(eng.bm.ref), f"{tag}: pages still referenced after the drain: {[r for r in eng.bm.ref if r]}"
         assert eng.bm.hits <= eng.bm.queries, tag
         assert eng.bm.num_free() == pages or prefix or host, tag
+        assert len(set(eng.bm.free_ids)) == len(eng.bm.free_ids), f"{tag}: a page is on the free list twice"
+        assert not set(eng.bm.free_ids) & set(eng.bm.evictable), f"{tag}: a page is both free and cached"
         eng.shutdown()
