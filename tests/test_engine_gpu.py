@@ -599,3 +599,64 @@ def test_follow_up_turn_behind_a_long_cached_prefix_splits_its_key_range(monkeyp
     cos = torch.nn.functional.cosine_similarity
     assert cos(log_g[:1], log_u[:1]).item() > 0.9995 and cos(log_e[:1], log_u[:1]).item() > 0.9995
     assert got_e == got_u or cos(log_e, log_u).min().item() > 0.999
+
+
+@pytest.mark.parametrize("chunk", range(0, 72, 24))
+def test_random_load_keeps_page_accounting_sound(chunk):
+    """The CPU scheduler fuzz's scripts (arrivals, shared prefixes, aborts, pools small enough to
+    preempt) against the GPU engine, where copies to the pinned host tier really are asynchronous
+    and decode / small prefill steps replay graphs.  bf16 tokens depend on what shares a step, so
+    the check is the accounting: every request that was not aborted ends with the tokens it asked
+    for, and once drained no page holds a reference, sits on the free list twice, or is both free
+    and cached."""
+    import random
+
+    from test_scheduler_fuzz import _script
+
+    for seed in range(chunk, chunk + 24):
+        rng = random.Random(1000 + seed)
+        pages = rng.choice((8, 9, 10, 12, 16))
+        budget = rng.choice((64, 100, 256, 512))
+        chunked = rng.random() < 0.8
+        prefix = rng.random() < 0.7
+        host = rng.random() < 0.7
+        eager = rng.random() < 0.5
+        cfg = EngineConfig(
+            model="tiny-llama-gqa", device="cuda", dtype="bfloat16", max_model_len=1024,
+            max_num_seqs=rng.choice((2, 4, 8)), max_num_batched_tokens=budget,
+            num_gpu_blocks_override=pages, enable_chunked_prefill=chunked, enable_prefix_caching=prefix,
+            enforce_eager=eager, port=0,
+            kv_offload=KVOffloadConfig(local_cpu=True, max_local_cpu_gb=0.02) if host else KVOffloadConfig())
+        eng = LLMEngine(cfg)
+        script = [(a, p[: (pages - 3) * 64 - 16], m, ab) for a, p, m, ab in _script(rng)]
+        tag = f"seed {seed} pages {pages} budget {budget} chunked {chunked} prefix {prefix} host {host} eager {eager}"
+        live, aborted, step = {}, set(), 0
+        while step < 1500:
+            for i, (arrive, prompt, max_tokens, _ab) in enumerate(script):
+                if arrive == step:
+                    sp = SamplingParams(max_tokens=max_tokens, temperature=0, ignore_eos=True)
+                    live[i] = eng.add_request(prompt, sp, request_id=f"g{seed}-r{i}")
+            for i, (_a, _p, _m, ab) in enumerate(script):
+                if ab == step and i in live and i not in aborted:
+                    eng.abort(f"g{seed}-r{i}")
+                    aborted.add(i)
+            if eng.has_work():
+                eng.step()
+            elif step > max(a for a, *_ in script):
+                break
+            step += 1
+        assert not eng.has_work(), f"{tag}: did not drain"
+        for i, (_a, _prompt, max_tokens, _ab) in enumerate(script):
+            if i not in aborted:
+                assert len(live[i].output_ids) == max_tokens, f"{tag}: request {i}"
+        torch.cuda.synchronize()
+        if eng.connector is not None:
+            for _ in range(50):
+                eng.connector.poll()
+                if not any(eng.bm.ref):
+                    break
+        assert not any(eng.bm.ref), f"{tag}: pages still referenced: {[r for r in eng.bm.ref if r]}"
+        assert len(set(eng.bm.free_ids)) == len(eng.bm.free_ids), f"{tag}: a page is on the free list twice"
+        assert not set(eng.bm.free_ids) & set(eng.bm.evictable), f"{tag}: a page is both free and cached"
+        assert eng.bm.num_free() == pages or prefix or host, tag
+        eng.shutdown()
