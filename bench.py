@@ -336,8 +336,8 @@ async def run_phase(a, ctx, *, port0: int, routing: str, users_per_gpu: int, war
             for p in clients:
                 await loop.run_in_executor(None, wait_line, p, "READY")  # warm-up rounds done
 
-        prof0 = dict(engine.prof)
         await loop.run_in_executor(None, barrier)
+        prof0 = dict(engine.prof)  # after the barrier: the other ranks' replicas are still warming up before it
         t_start = time.time()
         outs = []
         if rank == 0:

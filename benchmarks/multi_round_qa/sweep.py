@@ -71,6 +71,8 @@ def main():
                     help="the 'naive' arm of the A/B: every turn recomputes its whole history")
     ap.add_argument("--no-chunked-prefill", action="store_true",
                     help="whole prompts in one step (the reference's benchmark configuration)")
+    ap.add_argument("--num-gpu-blocks", type=int, default=0,
+                    help="KV pages per replica (default: what fits); a small pool forces evictions to the tiers")
     ap.add_argument("--base-port", type=int, default=18300)
     ap.add_argument("--out", default="sweep.jsonl")
     ap.add_argument("--device", default="cuda")
@@ -91,6 +93,8 @@ def main():
                    "--disable-log-requests", "--log-level", "warning",
                    "--no-enable-prefix-caching" if a.no_prefix_caching else "--enable-prefix-caching",
                    "--no-enable-chunked-prefill" if a.no_chunked_prefill else "--enable-chunked-prefill"]
+            if a.num_gpu_blocks:
+                cmd += ["--num-gpu-blocks-override", str(a.num_gpu_blocks)]
             if a.device != "cuda":
                 cmd += ["--device", "cpu", "--dtype", "float32"]
             procs.append(subprocess.Popen(cmd, env=e, cwd=ROOT))
