@@ -97,6 +97,12 @@ class Scheduler:
             req.hashes.extend(chain_hashes(req.all_ids, self._salt(req), prev, len(req.hashes)))
 
     def _release(self, req: Request) -> None:
+        if req.load_event is not None:
+            # a reload from the lower tiers may still be writing these pages (an abort between
+            # admission and the first step): the compute stream waits for it, so whoever is given
+            # the pages next writes after the copy, not under it
+            req.load_event.wait()
+            req.load_event = None
         if req.pages:
             self.bm.free(req.pages)
         req.pages = []
