@@ -228,8 +228,9 @@ def test_disaggregated_prefill_two_hops():
     async def go():
         async with Stack(4, "disaggregated_prefill", labels=["prefill", "prefill", "decode", "decode"],
                          extra=["--prefill-model-labels", "prefill", "--decode-model-labels", "decode"]) as s:
+            talks = [f"conversation {i}: " + " ".join(f"w{i}x{j}" for j in range(200)) for i in range(4)]
             for i in range(4):
-                st, data, hdr = await s.chat(headers={"X-Request-Id": f"req-{i}"}, max_tokens=7)
+                st, data, hdr = await s.chat(talks[i], headers={"X-Request-Id": f"req-{i}"}, max_tokens=7)
                 assert st == 200 and data.count(b"Hello") == 7
             by_id = {}
             for rid, _, url in s.routes():
@@ -248,6 +249,11 @@ def test_disaggregated_prefill_two_hops():
                     assert q["max_tokens"] == 7 and q["kv_transfer_params"]["do_remote_prefill"]
             # both pools are used (the reference would pin one endpoint of each)
             assert all(len(e.requests) > 0 for e in s.engines)
+            # a follow-up turn of a conversation takes the same pair of replicas
+            st, _, _ = await s.chat(talks[2] + " and one more question", headers={"X-Request-Id": "req-2b"}, max_tokens=7)
+            assert st == 200
+            again = [url for rid, _, url in s.routes() if rid == "req-2b"]
+            assert again == by_id["req-2"]
     run(go())
 
 

@@ -196,6 +196,45 @@ def test_disaggregated_router_balances_pools():
         DisaggregatedPrefillRouter(["x"], ["y"]).route_request(eps, {}, {}, Req(), {"max_tokens": 1})
 
 
+def test_disaggregated_router_keeps_a_conversation_on_its_prefill_and_decode_replica():
+    """N x M pools: a follow-up turn goes to the prefill replica whose prefix cache holds the
+    history and to the decode replica that holds its pages; a burst of new conversations (nothing
+    in flight in the decode pool yet while all of them prefill) spreads evenly over both pools."""
+    import asyncio
+    import collections
+    import random
+
+    from vllm_production_stack_amd.router.stats import RequestStatsMonitor
+
+    run = asyncio.run
+    r = DisaggregatedPrefillRouter(["prefill"], ["decode"])
+    eps = [EP(f"http://p{i}", "prefill") for i in range(2)] + [EP(f"http://d{i}", "decode") for i in range(6)]
+    mon = RequestStatsMonitor(10.0)
+    rng = random.Random(1)
+    system = "You are a helpful assistant. " * 100
+    placed, pre, dec = {}, collections.Counter(), collections.Counter()
+    for u in range(36):
+        prompt = system + f"user {u} " + " ".join(str(rng.random()) for _ in range(500))
+        p, d = run(r.route_pair(eps, mon.get_request_stats(1.0), {"prompt": prompt}))
+        mon.on_new_request(p, f"r{u}", 1.0)  # the prefill hop is in flight, the decode hop not yet
+        placed[u] = (p, d, prompt)
+        pre[p] += 1
+        dec[d] += 1
+    assert set(pre.values()) == {18} and set(dec.values()) == {6}, (pre, dec)
+    for u in range(36):
+        p, d, prompt = placed[u]
+        assert run(r.route_pair(eps, mon.get_request_stats(2.0),
+                                {"messages": [{"role": "user", "content": prompt},
+                                              {"role": "assistant", "content": "an answer"},
+                                              {"role": "user", "content": "and then?"}]})) == (p, d)
+    # a replica that went away is forgotten: its conversations move on
+    r.forget_endpoint("http://d0")
+    live = [e for e in eps if e.url != "http://d0"]
+    moved = [run(r.route_pair(live, mon.get_request_stats(3.0), {"prompt": placed[u][2] + " more"}))
+             for u in range(36) if placed[u][1] == "http://d0"]
+    assert moved and all(d != "http://d0" for _, d in moved)
+
+
 # ---------------------------------------------------------------- stats
 def test_moving_average_window():
     m = MovingAverageMonitor(10)

@@ -48,6 +48,7 @@ from __future__ import annotations
 import ctypes
 import json
 import logging
+import urllib.error
 import urllib.request
 from ctypes import c_int, c_size_t, c_void_p
 
@@ -177,8 +178,18 @@ def _post(url: str, payload: dict, raw: bytes | None = None, timeout: float = 10
     if _api_key:
         headers["Authorization"] = f"Bearer {_api_key}"
     req = urllib.request.Request(url, data=data, headers=headers)
-    with urllib.request.urlopen(req, timeout=timeout) as r:
-        body = r.read()
+    try:
+        with urllib.request.urlopen(req, timeout=timeout) as r:
+            body = r.read()
+    except urllib.error.HTTPError as e:
+        # the peer says why in the body ("KV pool exhausted", "pages are not reserved", ...)
+        why = ""
+        try:
+            d = json.loads(e.read() or b"{}")
+            why = d.get("message") or (d.get("error") or {}).get("message", "")
+        except Exception:  # noqa: BLE001
+            pass
+        raise RuntimeError(f"{url.rsplit('/', 1)[-1]}: HTTP {e.code} {why}".rstrip()) from None
     return json.loads(body) if body else {}
 
 

@@ -252,10 +252,13 @@ async def _route_disaggregated_prefill(state, request: web.Request, endpoint: st
     engine_stats = state.engine_stats_scraper.get_engine_stats()
     router = state.router
     try:
-        prefill_url = router.route_request(endpoints, engine_stats, request_stats, request,
-                                           {"max_tokens": 1})
-        decode_url = router.route_request(endpoints, engine_stats, request_stats, request,
-                                          {"max_tokens": 0})
+        if hasattr(router, "route_pair"):  # both hops follow the conversation
+            prefill_url, decode_url = await router.route_pair(endpoints, request_stats, request_json)
+        else:
+            prefill_url = router.route_request(endpoints, engine_stats, request_stats, request,
+                                               {"max_tokens": 1})
+            decode_url = router.route_request(endpoints, engine_stats, request_stats, request,
+                                              {"max_tokens": 0})
     except ValueError as e:
         return _json_error(503, str(e), request_id)
 

@@ -156,7 +156,7 @@ class PrefixAwareRouter(RoutingInterface):
         self._local_turn += 1
         return self._local_turn
 
-    def _least_loaded(self, urls: list[str], request_stats) -> str:
+    def _least_loaded(self, urls: list[str], request_stats, turn: int | None = None) -> str:
         def load(u):
             st = request_stats.get(u) if request_stats else None
             return 0 if st is None else st.in_prefill_requests + st.in_decoding_requests
@@ -166,17 +166,17 @@ class PrefixAwareRouter(RoutingInterface):
         if len(equals) == 1:
             return equals[0]
         # the first of the equals at or after the rotating position in the (sorted) candidate list
-        start = self._next_turn() % len(urls)
+        start = (self._next_turn() if turn is None else turn) % len(urls)
         for k in range(len(urls)):
             u = urls[(start + k) % len(urls)]
             if u in equals:
                 return u
         return equals[0]
 
-    def _choose(self, prompt, available, matched_len, matched, request_stats) -> str:
+    def _choose(self, prompt, available, matched_len, matched, request_stats, turn: int | None = None) -> str:
         strong = matched and matched_len >= self.min_match_ratio * len(prompt)
         candidates = sorted(matched) if strong else sorted(available)
-        return self._least_loaded(candidates, request_stats)
+        return self._least_loaded(candidates, request_stats, turn)
 
     def route_request(self, endpoints, engine_stats, request_stats, request, request_json=None):
         prompt = extract_prompt_text(request_json or {})
@@ -188,10 +188,21 @@ class PrefixAwareRouter(RoutingInterface):
         self.hashtrie.insert(prompt, selected)
         return selected
 
-    async def _route_shared(self, prompt, available, request_stats) -> str:
+    async def _route_shared(self, prompt, available, request_stats, turn: int | None = None) -> str:
         matched_len, matched = await self.shared.longest_prefix_match(prompt, available)
-        selected = self._choose(prompt, available, matched_len, matched, request_stats)
+        selected = self._choose(prompt, available, matched_len, matched, request_stats, turn)
         await self.shared.insert(prompt, selected)
+        return selected
+
+    async def pick(self, prompt: str, urls: set[str], request_stats, turn: int | None = None) -> str:
+        """The endpoint among ``urls`` for ``prompt`` (and remember the choice): what
+        ``route_request`` does, for callers that keep several pools in one trie.  ``turn``: the
+        rotation position to break ties with (default: the next one)."""
+        if self.shared is not None:
+            return await self._route_shared(prompt, urls, request_stats, turn)
+        matched_len, matched = self.hashtrie.longest_prefix_match(prompt, urls)
+        selected = self._choose(prompt, urls, matched_len, matched, request_stats, turn)
+        self.hashtrie.insert(prompt, selected)
         return selected
 
     def forget_endpoint(self, url: str) -> None:
@@ -314,14 +325,22 @@ class KvawareRouter(RoutingInterface):
 
 
 class DisaggregatedPrefillRouter(RoutingInterface):
-    """Two pools selected by model label; within a pool the least-loaded endpoint (fewest
-    router-tracked in-flight requests, then lowest QPS) is chosen, so N prefill x M decode
-    deployments are balanced."""
+    """Two pools selected by model label.  A conversation stays where its KV is: the prefill
+    replica that computed the earlier turns has them in its prefix cache, and the decode replica
+    that answered them holds their pages, so a follow-up turn recomputes and ships only what is
+    new.  Both choices therefore go through one prefix trie (``route_pair``); a prompt that matches
+    nothing long enough (a new conversation: at most the shared system prompt) takes the
+    least-loaded endpoint of the pool (fewest router-tracked in-flight requests, equals in a
+    rotation shared by all router workers), so N prefill x M decode deployments stay balanced.
+    The reference runs one replica of each (/root/reference/src/vllm_router/service_discovery.py:321-341),
+    where neither question arises."""
 
-    def __init__(self, prefill_model_labels: list[str], decode_model_labels: list[str]):
+    def __init__(self, prefill_model_labels: list[str], decode_model_labels: list[str],
+                 prefix_trie_max_nodes: int = 4_000_000):
         self.prefill_model_labels = prefill_model_labels or []
         self.decode_model_labels = decode_model_labels or []
         self._rr = 0
+        self._affinity = PrefixAwareRouter(prefix_trie_max_nodes)
 
     def _pick(self, pool, request_stats) -> str:
         def load(e):
@@ -335,13 +354,35 @@ class DisaggregatedPrefillRouter(RoutingInterface):
         self._rr += 1
         return ties[self._rr % len(ties)]
 
-    def route_request(self, endpoints, engine_stats, request_stats, request, request_json=None):
-        is_prefill = bool(request_json) and request_json.get("max_tokens", 0) == 1
-        labels = self.prefill_model_labels if is_prefill else self.decode_model_labels
+    def _pool(self, endpoints, prefill: bool):
+        labels = self.prefill_model_labels if prefill else self.decode_model_labels
         pool = [e for e in endpoints if e.model_label in labels]
         if not pool:
-            raise ValueError(f"no {'prefill' if is_prefill else 'decode'} endpoint with labels {labels}")
-        return self._pick(pool, request_stats)
+            raise ValueError(f"no {'prefill' if prefill else 'decode'} endpoint with labels {labels}")
+        return pool
+
+    def route_request(self, endpoints, engine_stats, request_stats, request, request_json=None):
+        """Load-only choice within one pool (``max_tokens == 1`` marks the prefill hop)."""
+        is_prefill = bool(request_json) and request_json.get("max_tokens", 0) == 1
+        return self._pick(self._pool(endpoints, is_prefill), request_stats)
+
+    async def route_pair(self, endpoints, request_stats, request_json) -> tuple[str, str]:
+        """(prefill url, decode url) for a request, with conversation affinity in both pools."""
+        prompt = extract_prompt_text(request_json or {})
+        pre = {e.url for e in self._pool(endpoints, True)}
+        dec = {e.url for e in self._pool(endpoints, False)}
+        # one rotation position per request for both pools: a burst of new conversations decides its
+        # decode replicas before any of them shows up in the decode pool's in-flight counts, so the
+        # rotation alone spreads them, and it must step by one per request in either pool
+        turn = self._affinity._next_turn()
+        return (await self._affinity.pick(prompt, pre, request_stats, turn),
+                await self._affinity.pick(prompt, dec, request_stats, turn))
+
+    def forget_endpoint(self, url: str) -> None:
+        self._affinity.forget_endpoint(url)
+
+    async def close(self) -> None:
+        await self._affinity.close()
 
 
 def initialize_routing_logic(routing_logic, *, session_key=None, lmcache_controller_port=9000,
@@ -363,5 +404,5 @@ def initialize_routing_logic(routing_logic, *, session_key=None, lmcache_control
         return PrefixAwareRouter(prefix_trie_max_nodes)
     if rl is RoutingLogic.DISAGGREGATED_PREFILL:
         logger.info("Initializing disaggregated prefill routing logic")
-        return DisaggregatedPrefillRouter(prefill_model_labels, decode_model_labels)
+        return DisaggregatedPrefillRouter(prefill_model_labels, decode_model_labels, prefix_trie_max_nodes)
     raise ValueError(f"Invalid routing logic {routing_logic}")
