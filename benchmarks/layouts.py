@@ -298,7 +298,7 @@ def run_multimodel(a, n_dense: int = 6, tp: int = 2) -> dict:
             "--static-backends", ",".join(f"http://127.0.0.1:{p}" for _, _, p in engines),
             "--static-models", ",".join(m for _, m, _ in engines),
             "--routing-logic", "kvaware", "--lmcache-controller-port", str(ctl), "--session-key", "x-user-id",
-            "--kv-aware-threshold", "256", "--engine-stats-interval", "2", "--log-level", "info"])
+            "--kv-aware-threshold", "256", "--kv-aware-fallback", "load", "--engine-stats-interval", "2", "--log-level", "info"])
         _wait_http(f"http://127.0.0.1:{rp}/health", 60, router)
         for i, (name, model, port) in enumerate(engines):
             env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LMCACHE_REMOTE_URL=f"lm://127.0.0.1:{cp}",

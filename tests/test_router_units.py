@@ -182,6 +182,41 @@ def test_kvaware_routes_to_holder_else_session_fallback():
     assert ctrl.lookup(chain_hashes(toks)) == {"inst-b": 5 * 64}
 
 
+def test_kvaware_load_fallback_deals_new_conversations_out_evenly():
+    """``--kv-aware-fallback load``: a prompt no replica holds goes to the replica with the fewest
+    requests in flight, equals in rotation (12 new conversations on 6 replicas: 2 each; the
+    session ring of the reference deals them out binomially), and a conversation whose pages a
+    replica reported stays with that replica."""
+    import collections
+
+    from vllm_production_stack_amd.controller import KVController
+    from vllm_production_stack_amd.engine.block_manager import chain_hashes
+    from vllm_production_stack_amd.router.stats import RequestStatsMonitor
+
+    ctrl = KVController()
+    eps = [EP(f"http://e{i}") for i in range(6)]
+    for i in range(6):
+        ctrl.register(f"inst-{i}", f"http://e{i}")
+    r = KvawareRouter(ctrl, session_key="x-user-id", kv_aware_threshold=100, controller_port=0,
+                      tokenize=lambda rj: rj["tokens"], fallback="load")
+    mon = RequestStatsMonitor(10.0)
+    got = collections.Counter()
+    where = {}
+    for u in range(12):
+        toks = list(range(1000 * u, 1000 * u + 640))
+        url = asyncio.run(r.route_request(eps, {}, mon.get_request_stats(1.0), Req({"x-user-id": str(u)}),
+                                          {"tokens": toks}))
+        mon.on_new_request(url, f"r{u}", 1.0)
+        got[url] += 1
+        where[u] = url
+        ctrl.admit("inst-" + url[-1], chain_hashes(toks))
+    assert set(got.values()) == {2}, got
+    for u in range(12):
+        toks = list(range(1000 * u, 1000 * u + 640)) + [7, 8, 9]
+        assert asyncio.run(r.route_request(eps, {}, mon.get_request_stats(2.0), Req({"x-user-id": str(u)}),
+                                           {"tokens": toks})) == where[u]
+
+
 def test_disaggregated_router_balances_pools():
     r = DisaggregatedPrefillRouter(["prefill"], ["decode"])
     eps = [EP("http://p0", "prefill"), EP("http://p1", "prefill")] + \

@@ -103,6 +103,7 @@ def build_routing_logic(cfg, args):
         prefill_model_labels=parse_comma_separated_args(cfg.prefill_model_labels),
         decode_model_labels=parse_comma_separated_args(cfg.decode_model_labels),
         kv_aware_threshold=cfg.kv_aware_threshold or args.kv_aware_threshold,
+        kv_aware_fallback=getattr(args, "kv_aware_fallback", "session"),
         prefix_trie_max_nodes=args.prefix_trie_max_nodes)
 
 

@@ -110,6 +110,10 @@ def build_parser() -> argparse.ArgumentParser:
     a("--prefill-model-labels", default=None)
     a("--decode-model-labels", default=None)
     a("--kv-aware-threshold", type=int, default=2000)
+    a("--kv-aware-fallback", choices=["session", "load"], default="session",
+      help="kvaware routing, when no replica holds enough of the prompt: 'session' = consistent hash of the "
+           "session header (the reference's rule: replicas get a binomial share of new conversations), "
+           "'load' = fewest in-flight requests, equals in rotation (an even share)")
     # extensions beyond the reference flag set
     a("--max-failover-attempts", type=int, default=0,
       help="retry a request on another endpoint when the chosen one refuses the connection")

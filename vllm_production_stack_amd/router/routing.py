@@ -220,8 +220,17 @@ class KvawareRouter(RoutingInterface):
     """Route to the instance that already holds the longest KV prefix of the prompt."""
 
     def __init__(self, controller=None, session_key: str | None = None, kv_aware_threshold: int = 2000,
-                 controller_port: int = 9000, tokenize=None):
+                 controller_port: int = 9000, tokenize=None, fallback: str = "session"):
+        from . import workers
         from ..controller import KVController
+
+        # what to do when no replica holds enough of the prompt: "session" (the reference,
+        # /root/reference/src/vllm_router/routers/routing_logic.py:318-322: hash ring on the session
+        # header) or "load" (fewest in-flight requests, equals in rotation: new conversations are
+        # dealt out evenly instead of binomially)
+        self.fallback = fallback
+        self._turn = workers.shared_rr_counter()
+        self._local_turn = random.randrange(1 << 16)
 
         self.controller = controller or KVController()
         self.controller_port = controller_port
@@ -314,7 +323,9 @@ class KvawareRouter(RoutingInterface):
                 best_url, matched = max(by_url.items(), key=lambda kv: kv[1])
                 if matched >= max(len(tokens) - self.threshold, 0):
                     url = best_url
-        if url is None:
+        if url is None and self.fallback == "load":
+            url = self._least_loaded(sorted(e.url for e in endpoints), request_stats)
+        elif url is None:
             session_id = request.headers.get(self.session_key, None) if self.session_key else None
             self._update_hash_ring(endpoints)
             if session_id is None:
@@ -322,6 +333,9 @@ class KvawareRouter(RoutingInterface):
             else:
                 url = self.hash_ring.get_node(str(session_id))
         return url
+
+    _next_turn = PrefixAwareRouter._next_turn
+    _least_loaded = PrefixAwareRouter._least_loaded
 
 
 class DisaggregatedPrefillRouter(RoutingInterface):
@@ -388,7 +402,7 @@ class DisaggregatedPrefillRouter(RoutingInterface):
 def initialize_routing_logic(routing_logic, *, session_key=None, lmcache_controller_port=9000,
                              prefill_model_labels=None, decode_model_labels=None,
                              kv_aware_threshold=2000, prefix_trie_max_nodes=4_000_000,
-                             controller=None) -> RoutingInterface:
+                             controller=None, kv_aware_fallback="session") -> RoutingInterface:
     rl = RoutingLogic(routing_logic) if not isinstance(routing_logic, RoutingLogic) else routing_logic
     if rl is RoutingLogic.ROUND_ROBIN:
         logger.info("Initializing round-robin routing logic")
@@ -398,7 +412,8 @@ def initialize_routing_logic(routing_logic, *, session_key=None, lmcache_control
         return SessionRouter(session_key)
     if rl is RoutingLogic.KVAWARE:
         logger.info("Initializing kvaware routing logic")
-        return KvawareRouter(controller, session_key, kv_aware_threshold, lmcache_controller_port)
+        return KvawareRouter(controller, session_key, kv_aware_threshold, lmcache_controller_port,
+                             fallback=kv_aware_fallback)
     if rl is RoutingLogic.PREFIXAWARE:
         logger.info("Initializing prefix-aware routing logic")
         return PrefixAwareRouter(prefix_trie_max_nodes)
