@@ -154,6 +154,8 @@ class SyntheticTokenizer(BaseTokenizer):
                         sub = [self._word_id(x) for x in self._WORD.findall(w)]
                         ids.extend(sub)
                         continue
+                    if len(memo) >= 2_000_000:  # arbitrary text never repeats its words: start over
+                        memo.clear()
                     i = memo[w] = self._word_id(w)
                 ids.append(i)
         if add_special_tokens and (not ids or ids[0] != self.bos_token_id):

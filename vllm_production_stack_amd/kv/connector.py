@@ -76,7 +76,7 @@ class KVConnector:
         if self.remote is not None:
             log.info("remote KV tier: %s (keys under %s/)", off.remote_url, self.namespace)
         self.cfg_remote_url = off.remote_url
-        self.remote_known: set[int] = set()
+        self.remote_known = _BoundedSet(1_000_000)  # what the cache server is believed to hold
         self.remote_dropped = 0  # fresh pages given up on because the server stopped draining the ring
         self.loaded_from = {"host": 0, "disk": 0, "remote": 0}  # pages brought back into HBM, by tier
         # Raw (naive) pages of a GPU replica travel through a ring of pinned staging slots:
@@ -624,6 +624,32 @@ class _TorchEvent:
 
     def wait(self) -> None:
         self.ev.synchronize()
+
+
+class _BoundedSet:
+    """Insertion-ordered set that forgets its older half when it reaches ``limit`` entries.  The
+    belief about what a remote cache server holds may be stale either way (the server evicts on its
+    own): forgetting a page costs one redundant upload, remembering every page ever uploaded costs
+    memory without end on a replica that runs for weeks."""
+
+    def __init__(self, limit: int):
+        self.limit = limit
+        self._d: dict[int, None] = {}
+
+    def add(self, h: int) -> None:
+        self._d[h] = None
+        if len(self._d) >= self.limit:
+            for k in list(self._d)[: self.limit // 2]:
+                del self._d[k]
+
+    def discard(self, h: int) -> None:
+        self._d.pop(h, None)
+
+    def __contains__(self, h) -> bool:
+        return h in self._d
+
+    def __len__(self) -> int:
+        return len(self._d)
 
 
 class _ComputeFence:
