@@ -180,7 +180,11 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--cases", default="prefill_cold,prefill_warm,decode")
     ap.add_argument("--variants", default="2,3,4,5,6,7,-1", help="prefill kernels to time (-1 = automatic choice)")
+    ap.add_argument("--heads", default="", help="query,kv head counts instead of Llama-3-8B's 32,8 (e.g. 28,4: Qwen2.5-7B)")
     a = ap.parse_args()
+    if a.heads:
+        global N_Q, N_KV
+        N_Q, N_KV = (int(v) for v in a.heads.split(","))
     cases = a.cases.split(",")
     variants = tuple(int(v) for v in a.variants.split(","))
     if "prefill_cold" in cases:

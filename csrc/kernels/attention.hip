@@ -1055,9 +1055,14 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
     bx = lin / gridDim.y;
   }
   const int G = n_q / n_kv;
-  const int groups_per_kv = G >> 2;
+  // a group ratio that is not a multiple of 4 leaves the last workgroup of a KV head with fewer
+  // heads than waves: the spare waves recompute the last head (they share the K/V loads and the
+  // barriers) and store nothing
+  const int groups_per_kv = (G + 3) >> 2;
   const int kvh = by / groups_per_kv;
-  const int head = kvh * G + (by % groups_per_kv) * 4 + wave;
+  const int head_slot = (by % groups_per_kv) * 4 + wave;
+  const bool head_ok = head_slot < G;
+  const int head = kvh * G + (head_ok ? head_slot : G - 1);
 
   const int seq = tile_seq[bx];
   if (seq < 0) return;  // padding of a fixed-size work list (captured graphs): the whole workgroup leaves
@@ -1572,6 +1577,7 @@ __global__ __launch_bounds__(256, 1) void paged_prefill_kernel_v4(
   }
 
   mfma_drain();
+  if (!head_ok) return;  // (no barrier below)
   if (part >= 0) {
     // record = [2 row blocks][4 channel tiles][16 values][64 lanes] fp32, then [2][64] maxima and
     // [2][64] sums: lane-major, so that the combine kernel (same lane roles) reads it back whole
@@ -1621,8 +1627,10 @@ __global__ __launch_bounds__(256) void prefill_combine_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int by = blockIdx.y, rb = blockIdx.z >> 2, dt = blockIdx.z & 3;
-  const int G = n_q / n_kv, groups_per_kv = G >> 2;
-  const int head = (by / groups_per_kv) * G + (by % groups_per_kv) * 4 + wave;
+  const int G = n_q / n_kv, groups_per_kv = (G + 3) >> 2;
+  const int head_slot = (by % groups_per_kv) * 4 + wave;
+  if (head_slot >= G) return;  // a spare wave of the last head group
+  const int head = (by / groups_per_kv) * G + head_slot;
   const int row0 = cu_q[seq], q_len = cu_q[seq + 1] - row0;
   const int row = q0 + 32 * rb + r;
   const float* rec0 = split_ws + ((long)(part0 * gridDim.y + by) * 4 + wave) * SPLIT_REC_FLOATS;
@@ -1679,6 +1687,8 @@ VPSA_EXPORT int vpsa_prefill_tile_rows(int n_q, int n_kv, int want64) {
   const int v = g_prefill_variant;
   const bool gen3_ok = (G % 4) == 0;
   if (gen3_ok && (v >= 4 || (v < 0 && want64))) return 64;
+  // the fourth generation pads the last head group of other ratios with spare waves
+  if (G >= 3 && (v >= 8 || (v < 0 && want64))) return 64;
   return 32 * (4 / GP);
 }
 
@@ -1687,7 +1697,7 @@ VPSA_EXPORT int vpsa_prefill_tile_rows(int n_q, int n_kv, int want64) {
 VPSA_EXPORT int vpsa_prefill_fuses_rope(int n_q, int n_kv, int tile_rows) {
   if (n_kv <= 0 || n_q % n_kv != 0) return 0;
   const int v = g_prefill_variant;
-  return tile_rows == 64 && (n_q / n_kv) % 4 == 0 && (v < 0 || v >= 8);
+  return tile_rows == 64 && n_q / n_kv >= 3 && (v < 0 || v >= 8);
 }
 
 // rope: null = q is already rotated; else the [position][HEAD_DIM] fp32 table (cos of the 64
@@ -1708,8 +1718,9 @@ VPSA_EXPORT int vpsa_paged_prefill_split(const void* q, long q_stride, void* out
                                          hipStream_t stream);
 
 VPSA_EXPORT long vpsa_prefill_split_record_bytes(int n_q, int n_kv) {
-  // one record per (partial, head group of 4, head)
-  return (long)(n_q / 4) * 4 * SPLIT_REC_FLOATS * 4;
+  // one record per (partial, head group of 4, wave)
+  if (n_kv <= 0 || n_q % n_kv != 0) return -1;
+  return (long)n_kv * ((n_q / n_kv + 3) / 4) * 4 * SPLIT_REC_FLOATS * 4;
 }
 
 VPSA_EXPORT int vpsa_paged_prefill_rope(const void* q, long q_stride, void* out, long out_stride,
@@ -1736,7 +1747,6 @@ VPSA_EXPORT int vpsa_paged_prefill_split(const void* q, long q_stride, void* out
   if (rope != nullptr && !vpsa_prefill_fuses_rope(n_q, n_kv, tile_rows)) return -4;
   if (n_q % n_kv != 0) return -1;
   const int G = n_q / n_kv;
-  if (G == 3) return -1;  // the tile is 4 waves = GP heads x (4 / GP) row blocks: GP must divide 4
   const int GP = G < 4 ? G : 4;
   const float sl2 = scale * 1.4426950408889634f;
   int variant = g_prefill_variant;
@@ -1745,8 +1755,9 @@ VPSA_EXPORT int vpsa_paged_prefill_split(const void* q, long q_stride, void* out
   (const uint16_t*)q, q_stride, (uint16_t*)out, out_stride, (const uint16_t*)cache,             \
       page_stride, v_offset, block_tables, max_blocks, cu_q, ctx_lens, tile_seq, tile_q0, n_q,  \
       n_kv, sl2
-  if (tile_rows == 64 && G % 4 == 0) {  // (a ratio of 2 also has 64-row tiles: two waves per head)
+  if (tile_rows == 64 && G >= 3) {  // (a ratio of 2 also has 64-row tiles: two waves per head)
     if (variant >= 0 && variant < 4) return -2;
+    if (G % 4 != 0 && variant >= 4 && variant < 8) return -2;  // the third generation has no spare-wave path
     static bool attr_set = false;
     if (!attr_set) {
       const void* fns[11] = {(const void*)paged_prefill_kernel_v4<true, true, 1>,
@@ -1765,7 +1776,7 @@ VPSA_EXPORT int vpsa_paged_prefill_split(const void* q, long q_stride, void* out
           return -3;
       attr_set = true;
     }
-    dim3 grid(num_tiles, n_kv * (G / 4)), block(256);
+    dim3 grid(num_tiles, n_kv * ((G + 3) / 4)), block(256);
     if (variant < 0) variant = many_tiles ? 11 : 10;
     if (tile_split != nullptr && variant < 8) return -4;
     if (variant >= 12 && variant <= 14) {
@@ -1801,11 +1812,12 @@ VPSA_EXPORT int vpsa_paged_prefill_split(const void* q, long q_stride, void* out
                          VPSA_PREFILL_ARGS);
     }
     if (tile_split != nullptr && num_groups > 0)
-      hipLaunchKernelGGL(prefill_combine_kernel, dim3(num_groups, n_kv * (G / 4), 8), block, 0, stream,
+      hipLaunchKernelGGL(prefill_combine_kernel, dim3(num_groups, n_kv * ((G + 3) / 4), 8), block, 0, stream,
                          (const float*)split_ws, groups, (uint16_t*)out, out_stride, cu_q, n_q, n_kv);
     return 0;
   }
   if (tile_split != nullptr) return -4;
+  if (G == 3) return -1;  // 4 waves = GP heads x (4 / GP) row blocks: GP must divide 4 (64-row tiles take a ratio of 3)
   if (tile_rows != 32 * (4 / GP) || variant >= 4) return -2;
   dim3 grid(num_tiles, n_kv * ((G + GP - 1) / GP)), block(256);
   if (variant < 0) variant = many_tiles ? 3 : 2;

@@ -37,7 +37,7 @@ def test_native_library_is_what_runs():
     assert ops.native_loaded(), "libvpsa_kernels.so must be loaded on a GPU box"
 
 
-@pytest.mark.parametrize("model", ["tiny-llama-gqa", "tiny-mixtral", "tiny-qwen2"])
+@pytest.mark.parametrize("model", ["tiny-llama-gqa", "tiny-mixtral", "tiny-qwen2", "tiny-llama-gqa3"])
 def test_graph_and_eager_decode_agree(model):
     ps = prompts(5, 200, seed=1)
     a = gpu_engine(model).generate(ps, copy.deepcopy(SP))
@@ -99,7 +99,8 @@ def _pin_moe_routing(monkeypatch):
     monkeypatch.setattr(ops, "moe_topk_softmax", topk)
 
 
-@pytest.mark.parametrize("model", ["tiny-llama-gqa", "tiny-qwen2", "tiny-mixtral", "tiny-opt-hd64", "tiny-llama-hd64"])
+@pytest.mark.parametrize("model", ["tiny-llama-gqa", "tiny-qwen2", "tiny-mixtral", "tiny-opt-hd64", "tiny-llama-hd64",
+                                   "tiny-llama-gqa3"])
 def test_gpu_matches_cpu_reference_logits(model, monkeypatch):
     """bf16 HIP path against the fp32 PyTorch path on the same weights, on EVERY prompt: the logits
     of the last prompt position (the whole prefill: embedding, every layer's attention over the

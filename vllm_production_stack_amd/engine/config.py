@@ -133,6 +133,9 @@ PRESETS: dict[str, ModelConfig] = {
         bos_token_id=151643, eos_token_id=151645),
     "tiny-qwen2": ModelConfig(name="tiny-qwen2", num_heads=7, num_kv_heads=1, hidden_size=512,
                               intermediate_size=1024, num_layers=3, qkv_bias=True, norm_eps=1e-6),
+    # three query heads per KV head (Llama-3.2-3B's ratio), 128-channel heads
+    "tiny-llama-gqa3": ModelConfig(name="tiny-llama-gqa3", num_heads=6, num_kv_heads=2, hidden_size=768,
+                                   intermediate_size=1024, num_layers=3),
     "tiny-mixtral": ModelConfig(name="tiny-mixtral", architecture="mixtral", num_heads=4,
                                 num_kv_heads=2, hidden_size=256, intermediate_size=256,
                                 num_experts=4, num_experts_per_tok=2),

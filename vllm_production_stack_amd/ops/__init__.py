@@ -307,8 +307,9 @@ def prefill_split_record_bytes(n_q: int, n_kv: int) -> int:
 
 
 def prefill_splits_supported(n_q: int, n_kv: int, rows: int) -> bool:
-    """Only the 64-row kernels for GQA groups of 4 and multiples take split work lists."""
-    return PREFILL_SPLITS and rows == 64 and n_kv > 0 and n_q % n_kv == 0 and (n_q // n_kv) % 4 == 0
+    """Only the 64-row kernel (GQA ratios of 3 and up: workgroups of 4 heads, the last one of a KV
+    head padded with spare waves) takes split work lists."""
+    return PREFILL_SPLITS and rows == 64 and n_kv > 0 and n_q % n_kv == 0 and n_q // n_kv >= 3
 
 
 def _whole_cost(kts, head_groups):
@@ -349,7 +350,7 @@ def plan_prefill_splits(seqs, q0s, q_lens, ctx_lens, n_q, n_kv, rows, max_entrie
     list alone."""
     if not prefill_splits_supported(n_q, n_kv, rows) or not seqs:
         return None
-    head_groups = n_kv * (n_q // n_kv // 4)
+    head_groups = n_kv * ((n_q // n_kv + 3) // 4)
     if len(seqs) * head_groups > SPLIT_MAX_ROUNDS * TILE_CUS:
         return None
     kts = []
