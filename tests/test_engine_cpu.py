@@ -270,7 +270,7 @@ def test_prefill_split_planner_covers_every_key_tile_once():
         q_lens = [rng.randint(1, 200) for _ in range(n_seqs)]
         shared = rng.choice((None, 21000))  # equal histories: the part-filled last round is what gets cut
         ctx = [q + (shared or rng.choice((0, 100, 3000, 21000, 60000))) for q in q_lens]
-        n_q, n_kv = rng.choice(((32, 8), (8, 2), (64, 8), (16, 4)))
+        n_q, n_kv = rng.choice(((32, 8), (8, 2), (64, 8), (16, 4), (28, 4), (12, 4)))
         seqs, q0s = [], []
         for s in range(n_seqs):
             for q0 in range((q_lens[s] - 1) // 64 * 64, -1, -64):
@@ -312,4 +312,5 @@ def test_prefill_split_planner_covers_every_key_tile_once():
     cut = ops.plan_prefill_splits(list(range(40)), [0] * 40, [30] * 40, [21000] * 40, 32, 8, 64)
     assert cut is not None and len(cut[0]) * 8 % 256 <= 8 * 8
     assert ops.plan_prefill_splits([0], [0], [8], [300], 32, 8, 64) is None
-    assert ops.plan_prefill_splits([0], [0], [8], [21000], 12, 4, 64) is None  # group ratio 3: no 64-row kernel
+    assert ops.plan_prefill_splits([0], [0], [8], [21000], 12, 4, 64) is not None  # ratio 3: one padded head group
+    assert ops.plan_prefill_splits([0], [0], [8], [21000], 8, 4, 64) is None  # ratio 2: no 64-row kernel
