@@ -118,7 +118,8 @@ def test_pd_layout_runs_end_to_end_on_the_cpu():
     pre = r["prefill_pool"][0]
     assert pre["pushed_pages"] > 0 and pre["failed_pushes"] == 0 and pre["push_jobs"] >= 2 * 8
     assert sum(d["prefix_hit_tokens"] for d in r["decode_pool"]) > 0
-    assert set(r["kv_pushed_gb_by_transport"]) == {"tcp"}
+    # follow-up turns return to the decode replica that holds the conversation: nothing left to push
+    assert {"tcp"} <= set(r["kv_pushed_gb_by_transport"]) <= {"tcp", "resident"}
 
 
 def test_multimodel_layout_runs_end_to_end_on_the_cpu():
