@@ -61,7 +61,8 @@ def _default_base_port() -> int:
         mp = int(os.environ.get("MASTER_PORT", "0"))
     except ValueError:
         mp = 0
-    return 18100 + (mp % 500) * 40 if mp else 18100
+    # (below 32768, where the kernel starts handing out ports for outgoing connections)
+    return 18100 + (mp % 350) * 40 if mp else 18100
 
 
 def parse() -> argparse.Namespace:
