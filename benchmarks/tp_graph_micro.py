@@ -40,7 +40,8 @@ def _rank_main(rank, a, port, eager, q):
     init_parallel_from_env(a.tp, 1)
     cfg = EngineConfig(model=a.model, max_model_len=a.ctx + a.tokens + 64, max_num_seqs=a.batch,
                        max_num_batched_tokens=4096, num_gpu_blocks_override=a.batch * ((a.ctx + a.tokens) // 64 + 2),
-                       port=0, tensor_parallel_size=a.tp, enforce_eager=eager, gpu_memory_utilization=0.4)
+                       port=0, tensor_parallel_size=a.tp, enforce_eager=eager, gpu_memory_utilization=0.4,
+                       enable_expert_parallel=a.expert_parallel)
     eng = LLMEngine(cfg)
     if get_replica().is_driver:
         g = torch.Generator().manual_seed(1)
@@ -54,6 +55,7 @@ def _rank_main(rank, a, port, eager, q):
         wall = time.perf_counter() - t0
         d_steps = eng.prof["decode_only_steps"] - p0["decode_only_steps"]
         q.put({"mode": "eager" if eager else "graph", "model": a.model, "tp": a.tp, "batch": a.batch,
+               "expert_parallel": bool(getattr(eng.runner.model, "ep", False)),
                "ctx": a.ctx, "new_tokens": a.tokens, "wall_s": round(wall, 3), "decode_only_steps": d_steps,
                "ranks_share_cards": torch.cuda.device_count() < a.tp,
                "oneshot_failed": bool(get_tp().oneshot.failed()) if get_tp().oneshot else None})
@@ -100,9 +102,11 @@ def main():
     ap.add_argument("--ctx", type=int, default=1024)
     ap.add_argument("--tokens", type=int, default=136)
     ap.add_argument("--timeout", type=int, default=240)
+    ap.add_argument("--expert-parallel", action="store_true", help="whole experts per rank (mixture-of-experts models)")
+    ap.add_argument("--modes", default="eager,graph")
     a = ap.parse_args()
-    for eager in (True, False):
-        print(json.dumps(_measure_decode(a, eager)), flush=True)
+    for mode in a.modes.split(","):
+        print(json.dumps(_measure_decode(a, mode == "eager")), flush=True)
 
 
 if __name__ == "__main__":
