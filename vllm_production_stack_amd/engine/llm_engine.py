@@ -152,6 +152,7 @@ class LLMEngine:
         outputs: list[StepOutput] = []
         fresh_pages: list[tuple[int, int]] = []
         done: list[tuple[Request, str, float]] = []
+        n_generated = 0
         for s in out.decodes + out.prefills:
             req = s.req
             if s.start < req.prompt_len:
@@ -163,7 +164,7 @@ class LLMEngine:
                 continue
             tok, info = sampled[id(s)]
             req.output_ids.append(tok)
-            self.metrics.generation_tokens.inc()
+            n_generated += 1
             t = time.time()
             if req.first_token is None:
                 req.first_token = t
@@ -186,6 +187,8 @@ class LLMEngine:
         # reference would land on a free page that the next request is given).
         if self.connector is not None and fresh_pages:
             self.connector.store_pages(fresh_pages)
+        if n_generated:
+            self.metrics.generation_tokens.inc(n_generated)
         for req, reason, t in done:
             if self.connector is not None:
                 # while the request still owns its pages (P->D push reads them)

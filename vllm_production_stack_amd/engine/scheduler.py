@@ -270,6 +270,8 @@ class Scheduler:
         """Advance a sequence after its rows ran; returns newly full (hash, page) pairs."""
         req = seq.req
         req.num_computed = seq.start + seq.n
+        if req.num_computed // PAGE <= req.num_registered:
+            return []  # no page filled up in this step (63 of 64 decode steps)
         self._extend_hashes(req)
         n_full = min(req.num_computed // PAGE, len(req.hashes))
         fresh = []
