@@ -312,41 +312,53 @@ async def run_phase(a, ctx, *, port0: int, routing: str, users_per_gpu: int, war
             raise RuntimeError(f"engine start failed on rank(s) {failed_ranks}: {start_error!r}")
         await loop.run_in_executor(None, barrier)  # every replica is listening
 
+        # Whatever goes wrong with the router or the load generators (rank 0 only) is kept until
+        # every barrier of the phase has been passed: the other ranks wait at those barriers, and a
+        # rank 0 that left early would leave them there until the process group's timeout.
+        client_error = None
         if rank == 0:
-            import aiohttp
+            try:
+                import aiohttp
 
-            # only now: a router that starts before its backends logs a failed scrape for each
-            router, clients, workers = spawn_children(a, n, port0, routing, users_per_gpu, warm_users_per_gpu,
-                                                      rounds, warm_rounds, user_base)
-            procs.extend([router] + clients)
+                # only now: a router that starts before its backends logs a failed scrape for each
+                router, clients, workers = spawn_children(a, n, port0, routing, users_per_gpu, warm_users_per_gpu,
+                                                          rounds, warm_rounds, user_base)
+                procs.extend([router] + clients)
 
-            async with aiohttp.ClientSession() as s:
-                for _ in range(300):
-                    try:
-                        async with s.get(f"http://127.0.0.1:{port0}/health") as r:
-                            if r.status == 200:
-                                break
-                    except aiohttp.ClientError:
-                        pass
-                    await asyncio.sleep(0.1)
-                else:
-                    raise RuntimeError("router did not come up")
-            for p in clients:
-                p.stdin.write("WARMUP\n")
-                p.stdin.flush()
-            for p in clients:
-                await loop.run_in_executor(None, wait_line, p, "READY")  # warm-up rounds done
+                async with aiohttp.ClientSession() as s:
+                    for _ in range(300):
+                        try:
+                            async with s.get(f"http://127.0.0.1:{port0}/health") as r:
+                                if r.status == 200:
+                                    break
+                        except aiohttp.ClientError:
+                            pass
+                        await asyncio.sleep(0.1)
+                    else:
+                        raise RuntimeError("router did not come up")
+                for p in clients:
+                    p.stdin.write("WARMUP\n")
+                    p.stdin.flush()
+                for p in clients:
+                    await loop.run_in_executor(None, wait_line, p, "READY")  # warm-up rounds done
+            except Exception as e:  # noqa: BLE001
+                client_error = e
 
         await loop.run_in_executor(None, barrier)
         prof0 = dict(engine.prof)  # after the barrier: the other ranks' replicas are still warming up before it
         t_start = time.time()
         outs = []
-        if rank == 0:
-            for p in clients:
-                p.stdin.write("GO\n")
-                p.stdin.flush()
-            outs = [json.loads(await loop.run_in_executor(None, wait_line, p, "RESULT "))
-                    for p in clients]
+        if rank == 0 and client_error is None:
+            try:
+                if os.environ.get("VPSA_BENCH_FAIL_CLIENTS") == str(user_base):  # test hook
+                    raise RuntimeError("injected load generator failure")
+                for p in clients:
+                    p.stdin.write("GO\n")
+                    p.stdin.flush()
+                outs = [json.loads(await loop.run_in_executor(None, wait_line, p, "RESULT "))
+                        for p in clients]
+            except Exception as e:  # noqa: BLE001
+                client_error = e
         await loop.run_in_executor(None, barrier)
         elapsed = time.time() - t_start
         # what every replica did in the timed region (shows how evenly the router spread the users)
@@ -374,7 +386,7 @@ async def run_phase(a, ctx, *, port0: int, routing: str, users_per_gpu: int, war
             # the reference's procedure against the same stack: requests arrive at a fixed rate,
             # sessions are pre-aged and new users keep joining (multi-round-qa.py's main loop)
             prof1 = dict(engine.prof)
-            if rank == 0:
+            if rank == 0 and client_error is None:
                 open_loop_result = await loop.run_in_executor(None, run_open_loop_client, a, port0, n, open_loop)
                 if "error" not in open_loop_result:
                     # what the engine did during this phase alone: how its steps ran (graphs or eager
@@ -385,6 +397,8 @@ async def run_phase(a, ctx, *, port0: int, routing: str, users_per_gpu: int, war
             await loop.run_in_executor(None, barrier)
         if rank != 0:
             return None
+        if client_error is not None:
+            raise client_error
 
         sys.path.insert(0, os.path.join(ROOT, "benchmarks", "multi_round_qa"))
         import multi_round_qa as mrq

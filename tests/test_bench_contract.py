@@ -133,3 +133,24 @@ def test_multimodel_layout_runs_end_to_end_on_the_cpu():
     assert r["conversations_kept_on_one_replica"] == r["conversations"] == 14
     assert any(e["model"] == "tiny-mixtral" and e["rows"] > 0 for e in r["per_replica"])
     assert r["cache_server"]["pages_known"] > 0
+
+
+def test_a_failing_load_generator_in_the_second_phase_does_not_strand_the_other_ranks():
+    """Rank 0 loses its load generators in the reference-configuration phase (injected).  The
+    other ranks wait at that phase's barriers: rank 0 must still pass them, so the run ends at
+    once on every rank, with the headline result intact and the failure recorded in its place."""
+    import time
+
+    env = dict(os.environ, OMP_NUM_THREADS="1", VPSA_BENCH_FAIL_CLIENTS="20000000")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29743", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--base-port", "19940"] + SMALL
+    t0 = time.time()
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert time.time() - t0 < 300
+    res = _one_json_line(p.stdout)
+    assert res["value"] > 0 and res["failed_requests"] == 0
+    assert "injected load generator failure" in res["reference_config"]["error"]
