@@ -484,7 +484,12 @@ class EngineServer:
         tot = {"n_out": 0, "cached": 0, "queue_time": 0.0, "t_first": None, "reason": None}
         resp = web.StreamResponse(status=200, headers={
             "Content-Type": "text/event-stream", "Cache-Control": "no-cache", "X-Request-Id": rid})
-        await resp.prepare(request)
+        try:
+            await resp.prepare(request)
+        except (ConnectionError, OSError):  # ClientConnectionResetError is one: gone before the headers
+            log.debug("client of %s hung up before the response began", rid)
+            self._end_span(span, t0, None, 0, 0, 0.0, "abort", "client disconnected")
+            return resp
         created = int(time.time())
         cid = ("chatcmpl-" if kind == "chat" else "cmpl-") + rid
         obj = "chat.completion.chunk" if kind == "chat" else "text_completion"
