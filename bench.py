@@ -514,6 +514,10 @@ async def rank_main(a: argparse.Namespace) -> None:
         ref = None
         if a.reference_rounds > 0:
             release_gpu_memory()
+            if gloo is not None:
+                # every rank has let go of the first phase's memory before any rank allocates for the
+                # second one (matters when a rehearsal puts several ranks on one card)
+                await asyncio.get_running_loop().run_in_executor(None, lambda: dist.barrier(group=gloo))
             offload_gb = reference_offload_gb(a, world)
             try:
                 ref = await run_phase(
