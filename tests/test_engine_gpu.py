@@ -710,3 +710,43 @@ def test_adapters_on_the_gpu_match_merged_weights_in_a_mixed_batch(tmp_path):
     assert cos(first[0], plain[0][0], dim=0).item() < 0.98
     assert cos(first[2], want["a1"][0][2], dim=0).item() < 0.98
     assert eng.runner._graphs, "decode steps with adapters replay graphs"
+
+
+def test_several_decode_steps_per_launch_generate_the_same_tokens():
+    """``--num-scheduler-steps 4``: decode-only greedy steps run four graph replays back to back,
+    the sampled ids feeding the next replay on the device.  Same tokens as one step at a time:
+    across page boundaries, with answer lengths that are not multiples of four, with a row that
+    stops on a stop token in the middle of a run (the rest of its run is dropped), with a request
+    that arrives while others decode, and a follow-up turn finds the pages filled during runs in
+    the prefix cache."""
+    ps = prompts(4, 120, seed=80)  # 120 + 9 crosses a page boundary inside a run
+    lens = [9, 14, 23, 6]
+
+    def run(steps):
+        eng = gpu_engine("tiny-llama-gqa", pages=128, num_scheduler_steps=steps)
+        sps = [SamplingParams(max_tokens=n, temperature=0, ignore_eos=True) for n in lens]
+        first = eng.generate(ps, sps)
+        # a stop token that the third row is known to produce, in the middle of its answer
+        stop_tok = first[2][9]
+        sp_stop = SamplingParams(max_tokens=23, temperature=0, ignore_eos=True, stop_token_ids=[stop_tok])
+        stopped = eng.generate([ps[2]], sp_stop)[0]
+        # a late arrival: one request decoding, another one joins after a few steps
+        a = eng.add_request(prompts(1, 70, seed=81)[0], SamplingParams(max_tokens=30, temperature=0, ignore_eos=True))
+        for _ in range(3):
+            eng.step()
+        b = eng.add_request(prompts(1, 50, seed=82)[0], SamplingParams(max_tokens=11, temperature=0, ignore_eos=True))
+        while eng.has_work():
+            eng.step()
+        follow = eng.generate([ps[1] + first[1] + [17, 18, 19]], SamplingParams(max_tokens=5, temperature=0, ignore_eos=True))
+        kinds = dict(eng.runner.step_kinds)
+        hits = eng.bm.hits
+        return first, stopped, a.output_ids, b.output_ids, follow, kinds, hits
+
+    one = run(1)
+    four = run(4)
+    assert four[:5] == one[:5]
+    assert [len(o) for o in four[0]] == lens
+    assert len(four[1]) <= 10 and four[1][-1] == one[0][2][9]
+    assert one[5]["decode_graph_follow_ups"] == 0 and four[5]["decode_graph_follow_ups"] > 10
+    assert four[5]["decode_graph"] < one[5]["decode_graph"]
+    assert four[6] == one[6] and four[6] > 0  # the same pages were found cached

@@ -362,6 +362,9 @@ class EngineConfig:
     tensor_parallel_size: int = 1
     pipeline_parallel_size: int = 1
     enable_expert_parallel: bool = False  # MoE layers: whole experts per tensor-parallel rank
+    # decode steps launched back to back before the host looks at the sampled tokens (greedy
+    # decode-only batches of a single-rank replica with nothing waiting; 1 = every step)
+    num_scheduler_steps: int = 1
     distributed_executor_backend: str | None = None
     enable_lora: bool = False
     max_loras: int = 1

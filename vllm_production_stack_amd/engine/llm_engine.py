@@ -21,7 +21,7 @@ from .config import EngineConfig, resolve_model
 from .metrics import EngineMetrics
 from .model_runner import ModelRunner
 from .request import Request, RequestState, SamplingParams, StepOutput
-from .scheduler import Scheduler
+from .scheduler import ScheduledSeq, Scheduler
 from .tokenizer import load_tokenizer
 
 log = logging.getLogger("vpsa.engine")
@@ -146,7 +146,8 @@ class LLMEngine:
             print("STEP dec=%d pre=%s free=%d" % (
                 len(out.decodes), [(s.start, s.n, len(s.req.pages)) for s in out.prefills],
                 self.bm.num_free()), file=sys.stderr, flush=True)
-        results = self.runner.execute(out)
+        k = self._decode_run_length(out)
+        results = self.runner.execute_decode_run(out.decodes, k) if k > 1 else self.runner.execute(out)
         t_c = time.perf_counter()
         sampled = {id(s): (tok, info) for s, tok, info in results}
         outputs: list[StepOutput] = []
@@ -162,22 +163,34 @@ class LLMEngine:
                 self.connector.on_chunk_computed(req)  # P->D: this chunk's pages leave now
             if id(s) not in sampled:
                 continue
-            tok, info = sampled[id(s)]
-            req.output_ids.append(tok)
-            n_generated += 1
+            toks, info = sampled[id(s)]
+            if not isinstance(toks, list):
+                toks = [toks]
             t = time.time()
-            if req.first_token is None:
-                req.first_token = t
-                self.metrics.ttft.observe(t - req.arrival)
-                if req.first_scheduled:
-                    self.metrics.queue_time.observe(req.first_scheduled - req.arrival)
-            elif req.last_token is not None:
-                self.metrics.tpot.observe(t - req.last_token)
+            # several tokens: the launch ran that many decode steps of this row back to back
+            gap = (t - req.last_token) / len(toks) if req.last_token is not None else None
+            emitted: list[int] = []
+            reason = None
+            for j, tok in enumerate(toks):
+                if j:  # the position of the previous token of this run has been computed as well
+                    fresh_pages.extend(self.scheduler.commit(ScheduledSeq(req, s.start + j, 1, True)))
+                req.output_ids.append(tok)
+                emitted.append(tok)
+                n_generated += 1
+                if req.first_token is None:
+                    req.first_token = t
+                    self.metrics.ttft.observe(t - req.arrival)
+                    if req.first_scheduled:
+                        self.metrics.queue_time.observe(req.first_scheduled - req.arrival)
+                elif gap is not None:
+                    self.metrics.tpot.observe(gap)
+                reason = self._stop_reason(req, tok)
+                if reason:
+                    break  # what the run computed past this token is dropped
             req.last_token = t
-            reason = self._stop_reason(req, tok)
             if reason:
                 done.append((req, reason, t))
-            outputs.append(StepOutput(req.request_id, [tok], reason is not None, reason,
+            outputs.append(StepOutput(req.request_id, emitted, reason is not None, reason,
                                       req.prompt_len, len(req.output_ids), req.num_cached_tokens + req.num_external_tokens,
                                       (req.first_scheduled - req.arrival) if req.first_scheduled else 0.0,
                                       [info] if info is not None else None))
@@ -203,7 +216,7 @@ class LLMEngine:
         pr = self.prof
         pr["steps"] += 1
         pr["decode_only_steps" if not out.prefills else "mixed_steps"] += 1
-        pr["rows"] += out.num_tokens
+        pr["rows"] += out.num_tokens + (k - 1) * len(out.decodes)
         pr["t_schedule"] += t_b - t_a
         pr["t_execute"] += t_c - t_b
         pr["t_post"] += time.perf_counter() - t_c
@@ -214,6 +227,28 @@ class LLMEngine:
         for kind, n in self.runner.step_kinds.items():  # how steps ran: captured graphs or eager launches
             pr["steps_" + kind] = n
         return outputs
+
+    def _decode_run_length(self, out) -> int:
+        """How many decode steps to launch back to back (``--num-scheduler-steps``): more than one
+        only for a decode-only step of plain greedy rows with nothing waiting to be admitted, every
+        row with that many tokens still to go and the pages for them in hand."""
+        k = self.cfg.num_scheduler_steps
+        if k <= 1 or out.prefills or not out.decodes or self.scheduler.waiting:
+            return 1
+        if not self.runner.decode_run_ok(out.decodes):
+            return 1
+        sampler = self.runner.sampler
+        for s in out.decodes:
+            req, p = s.req, s.req.params
+            if not p.greedy or p.logprobs is not None or sampler._needs_penalty(p) or req.pooling:
+                return 1
+            k = min(k, p.max_tokens - len(req.output_ids), self.max_model_len - req.num_tokens - 1)
+            if k <= 1:
+                return 1
+        for s in out.decodes:
+            if not self.scheduler._ensure_pages(s.req, s.start + k):
+                return 1  # (pages taken for rows before this one stay with their requests)
+        return k
 
     def _stop_reason(self, req: Request, tok: int) -> str | None:
         p = req.params

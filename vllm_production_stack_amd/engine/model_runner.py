@@ -85,7 +85,8 @@ class ModelRunner:
         self._graphs: dict[int, dict] = {}
         self._prefill_graphs: dict[int, dict] = {}
         # steps by how they ran (decode graph, prefill graph, both, eager)
-        self.step_kinds = {"decode_graph": 0, "prefill_graph": 0, "mixed_graphs": 0, "eager": 0}
+        self.step_kinds = {"decode_graph": 0, "decode_graph_follow_ups": 0, "prefill_graph": 0, "mixed_graphs": 0,
+                           "eager": 0}
         self._row_track: dict[tuple, dict] = {}  # driver: what each graph row's block table holds
         self._graph_pool = None
         self._pin = device.type == "cuda"
@@ -570,6 +571,61 @@ class ModelRunner:
         if self.distributed:
             check_collectives()
         return list(zip(decodes, toks, infos))
+
+    # ------------------------------------------------------------------ several decode steps per launch
+    def decode_run_ok(self, decodes: list[ScheduledSeq]) -> bool:
+        """Can ``execute_decode_run`` take these rows?  Single-rank graph decode without adapters."""
+        return bool(self.use_graphs and not self.distributed and self.device.type == "cuda" and decodes
+                    and len(decodes) <= _GRAPH_BUCKETS[-1] and all(s.samples for s in decodes)
+                    and (self.model.lora is None or all(s.req.lora_slot < 0 for s in decodes)))
+
+    def execute_decode_run(self, decodes: list[ScheduledSeq], k: int):
+        """``k`` greedy decode steps of the same rows in one go: the graph is replayed ``k`` times
+        without the host in between.  After each replay the sampled ids become the next input ids
+        on the device, and positions, slots and context lengths of the next step (known in advance:
+        every row simply advances by one token, its pages are already there) are copied from a
+        buffer sent up front.  The host reads all ``k`` x rows tokens back once, so the gap between
+        steps in which the GPU waits for scheduling and bookkeeping is paid once per ``k`` steps.
+        Returns (sequence, [k tokens], None) per row; the caller decides how many of them count
+        (a row that stops early simply ignores the rest: they were written into its own pages)."""
+        n = len(decodes)
+        ops.ensure_device()  # the calling thread may never have selected this process's GPU
+        self.step_kinds["decode_graph"] += 1
+        self.step_kinds["decode_graph_follow_ups"] += k - 1
+        st = self._launch_decode_graph(decodes)  # first replay is on the stream
+        bsz = st["ids"].shape[0]
+        nx = st.get("run")
+        if nx is None or nx["k"] < k:
+            dev = self.device
+            h64 = torch.zeros((max(k - 1, 1), bsz), dtype=torch.int64)
+            h32 = torch.zeros((max(k - 1, 1), 2, bsz), dtype=torch.int32)
+            if self._pin:
+                h64, h32 = h64.pin_memory(), h32.pin_memory()
+            nx = st["run"] = {"k": k, "h64": h64, "h32": h32, "n64": h64.numpy(), "n32": h32.numpy(),
+                              "d64": torch.zeros_like(h64, device=dev), "d32": torch.zeros_like(h32, device=dev),
+                              "hist": torch.zeros((k, bsz), dtype=torch.int64, device=dev)}
+        n64, n32 = nx["n64"], nx["n32"]
+        for j in range(1, k):
+            slots, pos, ctx = [-1] * bsz, [0] * bsz, [0] * bsz
+            for i, s in enumerate(decodes):
+                t = s.start + j
+                slots[i] = s.req.pages[t // PAGE] * PAGE + t % PAGE
+                pos[i] = t
+                ctx[i] = t + 1
+            n64[j - 1], n32[j - 1, 0], n32[j - 1, 1] = slots, pos, ctx
+        nx["d64"].copy_(nx["h64"], non_blocking=True)
+        nx["d32"].copy_(nx["h32"], non_blocking=True)
+        hist = nx["hist"]
+        for j in range(1, k):
+            hist[j - 1].copy_(st["toks"])
+            st["ids"].copy_(st["toks"])
+            st["slots"].copy_(nx["d64"][j - 1])
+            st["pos"].copy_(nx["d32"][j - 1, 0])
+            st["ctx"].copy_(nx["d32"][j - 1, 1])
+            st["graph"].replay()
+        hist[k - 1].copy_(st["toks"])
+        toks = hist[:k, :n].t().tolist()  # one read-back: [row][step]
+        return [(s, toks[i], None) for i, s in enumerate(decodes)]
 
     # ------------------------------------------------------------------ HIP-graph prefill parts
     def _prefill_graph_ok(self, prefills: list[ScheduledSeq]) -> bool:
