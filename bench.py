@@ -86,6 +86,8 @@ def parse() -> argparse.Namespace:
                     help="cap the HBM KV pool (pages of 64 tokens) to exercise the host tier; 0 = size from HBM")
     ap.add_argument("--prefill-step-ms", type=float, default=30.0,
                     help="engine's latency-aware prefill admission target (0 = token budget only)")
+    ap.add_argument("--num-scheduler-steps", type=int, default=1,
+                    help="decode steps per launch of the engines (see the engine's flag of the same name)")
     ap.add_argument("--packed-decode-weights", default="", choices=["", "auto", "on", "off"],
                     help="second copy of the MLP weights in matrix-core tile order for decode steps "
                          "(empty = the engine's default)")
@@ -509,6 +511,7 @@ async def rank_main(a: argparse.Namespace) -> None:
             warm_users_per_gpu=a.warmup_users_per_gpu, rounds=a.steps, warm_rounds=a.warmup, user_base=0,
             engine_kwargs=dict(max_num_batched_tokens=a.max_num_batched_tokens, enable_prefix_caching=True,
                                enable_chunked_prefill=True, kv_offload=off, prefill_step_ms=a.prefill_step_ms,
+                               num_scheduler_steps=a.num_scheduler_steps,
                                **({"packed_decode_weights": a.packed_decode_weights}
                                   if a.packed_decode_weights else {})))
         ref = None
