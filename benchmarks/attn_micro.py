@@ -28,10 +28,23 @@ N_Q, N_KV, HD, PAGE = 32, 8, 128, 64
 DEV = "cuda"
 
 
+PAGE_PAD = 0  # bytes between the end of a page and the start of the next (--page-pad-kb)
+LAYERS = 1  # layers per page of the pool (--layers 32: the engine's page, 8 MiB for Llama-3-8B)
+
+
 def make_pool(pages: int, seed: int = 0) -> torch.Tensor:
     g = torch.Generator(device=DEV).manual_seed(seed)
-    pool = torch.empty((pages, 1, 2, N_KV, PAGE * HD), device=DEV, dtype=torch.bfloat16)
-    pool.normal_(0.0, 1.0, generator=g)
+    if PAGE_PAD:  # pages PAGE_PAD bytes further apart than they are long
+        elems = LAYERS * 2 * N_KV * PAGE * HD
+        flat = torch.empty(pages * (elems + PAGE_PAD // 2), device=DEV, dtype=torch.bfloat16)
+        pool = flat.as_strided((pages, LAYERS, 2, N_KV, PAGE * HD),
+                               (elems + PAGE_PAD // 2, 2 * N_KV * PAGE * HD, N_KV * PAGE * HD, PAGE * HD, 1))
+    else:
+        pool = torch.empty((pages, LAYERS, 2, N_KV, PAGE * HD), device=DEV, dtype=torch.bfloat16)
+    if LAYERS == 1:
+        pool.normal_(0.0, 1.0, generator=g)
+    else:  # only the layer that is read needs values
+        pool[:, LAYERS // 2].normal_(0.0, 1.0, generator=g)
     return pool
 
 
@@ -162,10 +175,10 @@ def decode_case(n_seqs: int, ctx: int, iters: int) -> dict:
         ws_ml = torch.empty((n_seqs, N_Q, splits, 2), dtype=torch.float32, device=DEV)
 
         def run():
-            ops.paged_decode(q, out, pool, 0, bt, ctxs, N_Q, N_KV, HD, scale, splits, ws_o, ws_ml)
+            ops.paged_decode(q, out, pool, LAYERS // 2, bt, ctxs, N_Q, N_KV, HD, scale, splits, ws_o, ws_ml)
 
         entry = {}
-        for dv in (0, 1, 2):
+        for dv in (0, 1, 2, 3, 4, 5):  # 3-5: the same three with non-temporal K/V loads
             ops.set_decode_variant(dv)
             ms = timed(run, iters)
             entry[f"v{dv}"] = {"ms": round(ms, 4), "tb_per_s": round(kv_bytes / ms / 1e9, 3)}
@@ -180,8 +193,14 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--cases", default="prefill_cold,prefill_warm,decode")
     ap.add_argument("--variants", default="2,3,4,5,6,7,-1", help="prefill kernels to time (-1 = automatic choice)")
+    ap.add_argument("--layers", type=int, default=1,
+                    help="layers per page of the KV pool in the decode case (32: the engine's layout for Llama-3-8B)")
+    ap.add_argument("--page-pad-kb", type=int, default=0, help="decode case: spacing added between pages of the pool")
     ap.add_argument("--heads", default="", help="query,kv head counts instead of Llama-3-8B's 32,8 (e.g. 28,4: Qwen2.5-7B)")
     a = ap.parse_args()
+    global LAYERS, PAGE_PAD
+    LAYERS = a.layers
+    PAGE_PAD = a.page_pad_kb * 1024
     if a.heads:
         global N_Q, N_KV
         N_Q, N_KV = (int(v) for v in a.heads.split(","))

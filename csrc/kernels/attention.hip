@@ -1859,7 +1859,17 @@ VPSA_EXPORT int vpsa_paged_prefill(const void* q, long q_stride, void* out, long
 // wave takes both 32-key halves of a page together, so the two halves of every 128-byte V line
 // (64 keys of one channel) are requested back to back by the same wave instead of by two waves
 // that may have drifted apart by more than the caches hold.
-template <int MODE>
+template <bool NT>
+__device__ __forceinline__ u32x4 ld16(const uint16_t* p) {
+  const u32x4* q = reinterpret_cast<const u32x4*>(p);
+  return NT ? __builtin_nontemporal_load(q) : *q;
+}
+
+// NT: K/V fragments are fetched with non-temporal loads.  Every byte of a context is read once
+// per step and is gone from the caches long before the next one: the streaming policy keeps it
+// from displacing anything and reads the card's HBM 10-12 % faster than plain loads do
+// (`benchmarks/roof/roof_probe.py`: 6.9-7.1 against 6.2-6.3 TB/s).
+template <int MODE, bool NT>
 __global__ __launch_bounds__(256) void paged_decode_kernel(
     const uint16_t* __restrict__ q, long q_stride, uint16_t* __restrict__ out, long out_stride,
     const uint16_t* __restrict__ cache, long page_stride, long v_offset,
@@ -1922,11 +1932,10 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
-        kf[t][ks] = *reinterpret_cast<const u32x4*>(kp + ks * (PAGE * 32) + (koff + krow_base + 4 * t) * 32 +
-                                                    8 * g);
+        kf[t][ks] = ld16<NT>(kp + ks * (PAGE * 32) + (koff + krow_base + 4 * t) * 32 + 8 * g);
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt)
-      vf[dt] = *reinterpret_cast<const u32x4*>(vp + (koff >> 5) * (HEAD_DIM * 32) + (16 * dt + c16) * 32 + 8 * g);
+      vf[dt] = ld16<NT>(vp + (koff >> 5) * (HEAD_DIM * 32) + (16 * dt + c16) * 32 + 8 * g);
   };
   auto compute_chunk = [&](int c, u32x4 (&kf)[2][4], u32x4 (&vf)[8]) {
     f32x4 s_acc[2];
@@ -2100,24 +2109,23 @@ VPSA_EXPORT int vpsa_paged_decode(const void* q, long q_stride, void* out, long 
   if (n_q % n_kv != 0 || n_q / n_kv > 16 || num_splits < 1) return -1;
   if (num_splits > 1 && (!ws_o || !ws_ml)) return -1;
   dim3 grid(num_seqs, n_kv, num_splits), block(256);
-  const int variant = g_decode_variant >= 0 ? g_decode_variant : (num_splits >= 3 ? 1 : 0);
-  if (variant == 2) {
-    hipLaunchKernelGGL(paged_decode_kernel<2>, grid, block, 32768 + 512, stream,
-                       (const uint16_t*)q, q_stride, (uint16_t*)out, out_stride,
-                       (const uint16_t*)cache, page_stride, v_offset, block_tables, max_blocks,
-                       ctx_lens, (float*)ws_o, (float*)ws_ml, n_q, n_kv, num_splits,
-                       scale * 1.4426950408889634f);
-  } else if (variant == 1) {
-    hipLaunchKernelGGL(paged_decode_kernel<1>, grid, block, 32768 + 512, stream,
-                       (const uint16_t*)q, q_stride, (uint16_t*)out, out_stride,
-                       (const uint16_t*)cache, page_stride, v_offset, block_tables, max_blocks,
-                       ctx_lens, (float*)ws_o, (float*)ws_ml, n_q, n_kv, num_splits,
-                       scale * 1.4426950408889634f);
-  } else
-  hipLaunchKernelGGL(paged_decode_kernel<0>, grid, block, 32768 + 512, stream, (const uint16_t*)q,
-                     q_stride, (uint16_t*)out, out_stride, (const uint16_t*)cache, page_stride,
-                     v_offset, block_tables, max_blocks, ctx_lens, (float*)ws_o, (float*)ws_ml,
-                     n_q, n_kv, num_splits, scale * 1.4426950408889634f);
+  // variants 0-2: MODE with plain loads (kept for A/B), 3-5: MODE 0-2 with non-temporal loads
+  const int variant = g_decode_variant >= 0 ? g_decode_variant : (num_splits >= 3 ? 4 : 3);
+#define VPSA_DECODE(MODE, NT)                                                                       \
+  hipLaunchKernelGGL((paged_decode_kernel<MODE, NT>), grid, block, 32768 + 512, stream,             \
+                     (const uint16_t*)q, q_stride, (uint16_t*)out, out_stride,                      \
+                     (const uint16_t*)cache, page_stride, v_offset, block_tables, max_blocks,       \
+                     ctx_lens, (float*)ws_o, (float*)ws_ml, n_q, n_kv, num_splits,                  \
+                     scale * 1.4426950408889634f)
+  switch (variant) {
+    case 0: VPSA_DECODE(0, false); break;
+    case 1: VPSA_DECODE(1, false); break;
+    case 2: VPSA_DECODE(2, false); break;
+    case 3: VPSA_DECODE(0, true); break;
+    case 5: VPSA_DECODE(2, true); break;
+    default: VPSA_DECODE(1, true); break;
+  }
+#undef VPSA_DECODE
   if (num_splits > 1) {
     hipLaunchKernelGGL(decode_reduce_kernel, dim3(num_seqs, n_q), dim3(128), 0, stream,
                        (const float*)ws_o, (const float*)ws_ml, (uint16_t*)out, out_stride, n_q,

@@ -395,7 +395,7 @@ def test_paged_prefill_long_context(ql, prefix, variant):
 
 @pytest.mark.parametrize("n_q,n_kv", [(32, 8), (8, 8), (64, 8), (28, 4), (10, 2)])
 @pytest.mark.parametrize("splits", [1, 3, 8])
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, -1])
 def test_paged_decode_matches_reference(n_q, n_kv, splits, variant):
     torch.manual_seed(10)
     hd, layers = 128, 2
@@ -417,7 +417,7 @@ def test_paged_decode_matches_reference(n_q, n_kv, splits, variant):
     assert err < REL_TOL, err
 
 
-@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("variant", [0, 2, 4, -1])
 def test_paged_decode_bench_shape(variant):
     """The decode step of the headline bench: 40 sequences of ~22k keys each, their 345 pages
     scattered over a 14 000-page pool, the automatic split count."""

@@ -61,7 +61,8 @@ def set_prefill_variant(v: int) -> int:
 
 def set_decode_variant(v: int) -> int:
     """Select the decode attention kernel (-1: automatic by split count, 0: one register set per
-    wave, 1: software-pipelined with two register sets, 2: a wave takes both halves of a page).
+    wave, 1: software-pipelined with two register sets, 2: a wave takes both halves of a page;
+    3-5: the same three with non-temporal K/V loads, which the automatic choice takes).
     Returns the previous selection."""
     return int(_kernels().vpsa_set_decode_variant(c_int(v)))
 
