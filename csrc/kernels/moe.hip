@@ -208,8 +208,10 @@ __global__ __launch_bounds__(256) void moe_gemv_gate_up_kernel(
 #pragma unroll
     for (int r = 0; r < GEMV_ROWS; ++r) {
       const int n = n0 + r < inter ? n0 + r : inter - 1;
-      wg[r] = reinterpret_cast<const u32x4*>(wbase + (long)n * hidden)[c];
-      wu[r] = reinterpret_cast<const u32x4*>(wbase + (long)(inter + n) * hidden)[c];
+      // whole lines, read once per step: streaming loads (the matrix-core kernels below read half
+      // lines per step and need the cache to hold the other half: plain loads there, measured)
+      wg[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase + (long)n * hidden) + c);
+      wu[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase + (long)(inter + n) * hidden) + c);
     }
 #pragma unroll
     for (int r = 0; r < GEMV_ROWS; ++r) {
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256) void moe_gemv_down_kernel(
 #pragma unroll
     for (int r = 0; r < GEMV_ROWS; ++r) {
       const int h = h0 + r < hidden ? h0 + r : hidden - 1;
-      w[r] = reinterpret_cast<const u32x4*>(wbase + (long)h * inter)[c];
+      w[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase + (long)h * inter) + c);
     }
 #pragma unroll
     for (int r = 0; r < GEMV_ROWS; ++r) acc[r] += dot8(w[r], a);
