@@ -1,7 +1,8 @@
-"""HBM read roof of the card by loads in flight, cache policy, access pattern and grid size.
-Build first (on any machine with hipcc):
-    hipcc --offload-arch=gfx950 -O3 -shared -fPIC benchmarks/roof/roof_probe.hip -o benchmarks/roof/libroof_probe.so
-then  python benchmarks/roof/roof_probe.py   (one JSON line per variant, best grid size of each)."""
+"""HBM read roof of the card by loads in flight, cache policy, access pattern and grid size
+(`csrc/tools/roof_probe.hip`, built with the other native libraries).
+
+    python benchmarks/roof_probe.py        (one JSON line per variant, best grid size of each)
+"""
 import ctypes
 import json
 import os
@@ -9,8 +10,8 @@ import time
 
 import torch
 
-here = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(here, "libroof_probe.so"))
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+lib = ctypes.CDLL(os.path.join(root, "vllm_production_stack_amd", "_native", "libvpsa_roof_probe.so"))
 dev = torch.device("cuda", 0)
 buf = torch.empty(8 << 30, dtype=torch.uint8, device=dev).random_(0, 255)
 sink = torch.zeros(1, dtype=torch.int32, device=dev)

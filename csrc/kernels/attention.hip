@@ -1868,7 +1868,7 @@ __device__ __forceinline__ u32x4 ld16(const uint16_t* p) {
 // NT: K/V fragments are fetched with non-temporal loads.  Every byte of a context is read once
 // per step and is gone from the caches long before the next one: the streaming policy keeps it
 // from displacing anything and reads the card's HBM 10-12 % faster than plain loads do
-// (`benchmarks/roof/roof_probe.py`: 6.9-7.1 against 6.2-6.3 TB/s).
+// (`benchmarks/roof_probe.py`: 6.9-7.1 against 6.2-6.3 TB/s).
 template <int MODE, bool NT>
 __global__ __launch_bounds__(256) void paged_decode_kernel(
     const uint16_t* __restrict__ q, long q_stride, uint16_t* __restrict__ out, long out_stride,

@@ -37,6 +37,8 @@ TARGETS = {
     "vpsa_kvio": ("hip", ["kvio/kvio.cpp"], []),
     "vpsa_comm": ("hip", ["comm/comm.cpp"], ["-lrccl"]),
     "vpsa_routercore": ("cxx", ["routercore/routercore.cpp"], []),
+    # measurement tool, not part of the serving path: the card's HBM read roof (benchmarks/roof_probe.py)
+    "vpsa_roof_probe": ("hip", ["tools/roof_probe.hip"], []),
 }
 
 # extra compile flags for single sources.  attention.hip: the one-wave-per-SIMD prefill kernel keeps
