@@ -622,15 +622,17 @@ def test_random_load_keeps_page_accounting_sound(chunk):
         prefix = rng.random() < 0.7
         host = rng.random() < 0.7
         eager = rng.random() < 0.5
+        run = rng.choice((1, 1, 3))  # decode steps per launch
         cfg = EngineConfig(
-            model="tiny-llama-gqa", device="cuda", dtype="bfloat16", max_model_len=1024,
+            model="tiny-llama-gqa", device="cuda", dtype="bfloat16", max_model_len=1024, num_scheduler_steps=run,
             max_num_seqs=rng.choice((2, 4, 8)), max_num_batched_tokens=budget,
             num_gpu_blocks_override=pages, enable_chunked_prefill=chunked, enable_prefix_caching=prefix,
             enforce_eager=eager, port=0,
             kv_offload=KVOffloadConfig(local_cpu=True, max_local_cpu_gb=0.02) if host else KVOffloadConfig())
         eng = LLMEngine(cfg)
         script = [(a, p[: (pages - 3) * 64 - 16], m, ab) for a, p, m, ab in _script(rng)]
-        tag = f"seed {seed} pages {pages} budget {budget} chunked {chunked} prefix {prefix} host {host} eager {eager}"
+        tag = (f"seed {seed} pages {pages} budget {budget} chunked {chunked} prefix {prefix} host {host} "
+               f"eager {eager} run {run}")
         live, aborted, step = {}, set(), 0
         while step < 1500:
             for i, (arrive, prompt, max_tokens, _ab) in enumerate(script):
