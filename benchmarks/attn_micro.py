@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--variants", default="2,3,4,5,6,7,-1", help="prefill kernels to time (-1 = automatic choice)")
     ap.add_argument("--layers", type=int, default=1,
                     help="layers per page of the KV pool in the decode case (32: the engine's layout for Llama-3-8B)")
+    ap.add_argument("--decode-seqs", default="40", help="decode case: batch sizes (comma separated)")
     ap.add_argument("--page-pad-kb", type=int, default=0, help="decode case: spacing added between pages of the pool")
     ap.add_argument("--heads", default="", help="query,kv head counts instead of Llama-3-8B's 32,8 (e.g. 28,4: Qwen2.5-7B)")
     a = ap.parse_args()
@@ -221,7 +222,8 @@ def main():
                            (20, 150, 21000), (40, 128, 21000), (1, 1024, 8192), (1, 2048, 18000)):
             print(json.dumps(split_case(n, ql, pre, a.iters)), flush=True)
     if "decode" in cases:
-        print(json.dumps(decode_case(40, 21500, a.iters)), flush=True)
+        for n in (int(v) for v in a.decode_seqs.split(",")):
+            print(json.dumps(decode_case(n, 21500, a.iters)), flush=True)
 
 
 if __name__ == "__main__":

@@ -496,10 +496,15 @@ def dense_attention(q, k, v, heads: int, out=None):
 
 
 def decode_num_splits(num_seqs: int, n_kv: int, max_ctx: int) -> int:
-    """Enough workgroups to cover 256 CUs five times over (measured at 40 sequences x 8 KV heads x
-    21.5k keys: 4 splits = 1280 workgroups read 5.95 TB/s with the pipelined kernel, 3 splits the
-    same, 1 split 5.7), at least 256 keys per split."""
-    want = max(1, -(-1280 // max(1, num_seqs * n_kv)))
+    """Splits of the key range per (sequence, KV head).  Measured on 21.5k-token contexts in the
+    engine's page layout with streaming loads (`benchmarks/attn_micro.py --cases decode --layers 32
+    --decode-seqs 4,8,16,24,40,64`): batches of a few sequences read fastest with about one
+    workgroup per CU (4 sequences: 5.25 TB/s at 192 workgroups, 4.7 at 1024), larger ones with about
+    three (16 sequences: 6.5-6.6 TB/s at 512-768 workgroups, 40 sequences: 6.45 at 960, 6.35 at
+    640 or 1280); at least 256 keys per split."""
+    per_split = max(1, num_seqs * n_kv)
+    target = 256 if per_split < 96 else 768
+    want = max(1, -(-target // per_split))
     by_len = max(1, max_ctx // 256)
     return int(max(1, min(want, by_len, 32)))
 
