@@ -28,6 +28,7 @@ N_Q, N_KV, HD, PAGE = 32, 8, 128, 64
 DEV = "cuda"
 
 
+POOL_SPREAD = 1.0  # decode case: the pool is this many times larger than the pages that are read (--pool-spread)
 PAGE_PAD = 0  # bytes between the end of a page and the start of the next (--page-pad-kb)
 LAYERS = 1  # layers per page of the pool (--layers 32: the engine's page, 8 MiB for Llama-3-8B)
 
@@ -160,9 +161,10 @@ def split_case(n_seqs: int, q_len: int, prefix: int, iters: int) -> dict:
 
 def decode_case(n_seqs: int, ctx: int, iters: int) -> dict:
     pages_per_seq = (ctx + PAGE - 1) // PAGE
-    pool = make_pool(n_seqs * pages_per_seq + 1)
+    total = int((n_seqs * pages_per_seq) * POOL_SPREAD)
+    pool = make_pool(total + 1)
     g = torch.Generator().manual_seed(2)
-    perm = torch.randperm(n_seqs * pages_per_seq, generator=g).view(n_seqs, pages_per_seq)
+    perm = torch.randperm(total, generator=g)[: n_seqs * pages_per_seq].view(n_seqs, pages_per_seq)
     bt = perm.to(torch.int32).to(DEV)
     q = torch.randn((n_seqs, N_Q * HD), device=DEV).to(torch.bfloat16)
     out = torch.empty_like(q)
@@ -195,11 +197,14 @@ def main():
     ap.add_argument("--variants", default="2,3,4,5,6,7,-1", help="prefill kernels to time (-1 = automatic choice)")
     ap.add_argument("--layers", type=int, default=1,
                     help="layers per page of the KV pool in the decode case (32: the engine's layout for Llama-3-8B)")
+    ap.add_argument("--pool-spread", type=float, default=1.0,
+                    help="decode case: size of the pool relative to the pages read (they are scattered over all of it)")
     ap.add_argument("--decode-seqs", default="40", help="decode case: batch sizes (comma separated)")
     ap.add_argument("--page-pad-kb", type=int, default=0, help="decode case: spacing added between pages of the pool")
     ap.add_argument("--heads", default="", help="query,kv head counts instead of Llama-3-8B's 32,8 (e.g. 28,4: Qwen2.5-7B)")
     a = ap.parse_args()
-    global LAYERS, PAGE_PAD
+    global LAYERS, PAGE_PAD, POOL_SPREAD
+    POOL_SPREAD = a.pool_spread
     LAYERS = a.layers
     PAGE_PAD = a.page_pad_kb * 1024
     if a.heads:
