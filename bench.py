@@ -88,6 +88,9 @@ def parse() -> argparse.Namespace:
                     help="engine's latency-aware prefill admission target (0 = token budget only)")
     ap.add_argument("--num-scheduler-steps", type=int, default=1,
                     help="decode steps per launch of the engines (see the engine's flag of the same name)")
+    ap.add_argument("--kv-layer-groups", type=int, default=0,
+                    help="KV pool of the headline phase's engines as this many pools of consecutive layers "
+                         "(0 = the engine's choice; see the engine's flag of the same name)")
     ap.add_argument("--packed-decode-weights", default="", choices=["", "auto", "on", "off"],
                     help="second copy of the MLP weights in matrix-core tile order for decode steps "
                          "(empty = the engine's default)")
@@ -423,6 +426,7 @@ async def run_phase(a, ctx, *, port0: int, routing: str, users_per_gpu: int, war
             "round_times_s": [round(x, 3) for x in outs[0]["round_times"]] if outs else [],
             "per_replica": per_replica, "router_workers": workers, "open_loop": open_loop_result,
             "kv_pages_per_replica": engine.runner.num_pages,
+            "kv_layer_groups": len(getattr(engine.runner.pool, "groups", [0])),
             "kv_tiers": kv_tiers, "engine0_profile": prof_delta,
         }
     finally:
@@ -512,6 +516,7 @@ async def rank_main(a: argparse.Namespace) -> None:
             engine_kwargs=dict(max_num_batched_tokens=a.max_num_batched_tokens, enable_prefix_caching=True,
                                enable_chunked_prefill=True, kv_offload=off, prefill_step_ms=a.prefill_step_ms,
                                num_scheduler_steps=a.num_scheduler_steps,
+                               kv_layer_groups=a.kv_layer_groups,
                                **({"packed_decode_weights": a.packed_decode_weights}
                                   if a.packed_decode_weights else {})))
         ref = None
@@ -558,6 +563,7 @@ async def rank_main(a: argparse.Namespace) -> None:
                            "rounds": a.steps, "parallelism": f"dp{n} (replicas behind router)",
                            "routing": a.routing_logic, "router_workers": head["router_workers"],
                            "kv_pages_per_replica": head["kv_pages_per_replica"],
+                           "kv_layer_groups": head.get("kv_layer_groups", 1),
                            "cpu_offload_gb": a.cpu_offload_gb, "prefill_step_ms": a.prefill_step_ms},
                 "kv_tiers": head["kv_tiers"], "engine0_profile": head["engine0_profile"],
                 "per_replica": head["per_replica"],

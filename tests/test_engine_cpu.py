@@ -314,3 +314,31 @@ def test_prefill_split_planner_covers_every_key_tile_once():
     assert ops.plan_prefill_splits([0], [0], [8], [300], 32, 8, 64) is None
     assert ops.plan_prefill_splits([0], [0], [8], [21000], 12, 4, 64) is not None  # ratio 3: one padded head group
     assert ops.plan_prefill_splits([0], [0], [8], [21000], 8, 4, 64) is None  # ratio 2: no 64-row kernel
+
+
+def test_a_pool_cut_into_layer_groups_generates_the_same_tokens():
+    """``kv_layer_groups``: each group of layers keeps its K/V in a pool of its own; what attention
+    reads and writes is the same, and replicas whose pages leave the pool as a whole keep one pool."""
+    from vllm_production_stack_amd import ops
+    from vllm_production_stack_amd.engine.config import KVOffloadConfig
+
+    g = torch.Generator().manual_seed(5)
+    ps = [torch.randint(16, 500, (n,), generator=g).tolist() for n in (150, 70, 300)]
+    ps.append(ps[0][:128] + ps[1][:40])  # shares two pages with the first prompt
+    sp = SamplingParams(max_tokens=8, temperature=0, ignore_eos=True)
+    want = make_engine("tiny-llama-gqa", budget=96).generate(ps, copy.deepcopy(sp))
+    eng = make_engine("tiny-llama-gqa", budget=96, kv_layer_groups=3)  # the model has three layers
+    pool = eng.runner.pool
+    assert isinstance(pool, ops.LayerGroupedPool) and len(pool.groups) == 3
+    assert pool.shape == (64, 3, 2, eng.runner.n_kv_local, 64 * eng.runner.kv_head_dim)
+    assert eng.generate(ps, copy.deepcopy(sp)) == want
+    page = pool.page(3)
+    assert page.shape == pool.shape[1:] and page.abs().sum() > 0
+    pool.write_page(5, page)
+    assert torch.equal(pool.page(5), page)
+    # a host tier moves whole pages: the request is ignored there
+    assert isinstance(make_engine("tiny-llama-gqa", kv_layer_groups=2).runner.pool, torch.Tensor)  # 3 layers
+    tiered = make_engine("tiny-llama-gqa", kv_layer_groups=3,
+                         kv_offload=KVOffloadConfig(local_cpu=True, max_local_cpu_gb=0.01))
+    assert isinstance(tiered.runner.pool, torch.Tensor)
+    tiered.shutdown()

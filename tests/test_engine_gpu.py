@@ -752,3 +752,19 @@ def test_several_decode_steps_per_launch_generate_the_same_tokens():
     assert one[5]["decode_graph_follow_ups"] == 0 and four[5]["decode_graph_follow_ups"] > 10
     assert four[5]["decode_graph"] < one[5]["decode_graph"]
     assert four[6] == one[6] and four[6] > 0  # the same pages were found cached
+
+
+@pytest.mark.parametrize("model,groups", [("tiny-llama-gqa", 3), ("tiny-llama-hd64", 3), ("tiny-mixtral", 2)])
+def test_a_pool_cut_into_layer_groups_generates_the_same_tokens(model, groups):
+    """Graph decode, chunked prefill behind a cached prefix and mixed steps on a KV pool that is
+    one pool per group of layers: the same tokens as on whole pages."""
+    from vllm_production_stack_amd import ops
+
+    ps = prompts(6, 300, seed=11)
+    ps.append(ps[0][:256] + ps[1][:100])
+    sp = SamplingParams(max_tokens=12, temperature=0, ignore_eos=True)
+    want = gpu_engine(model, budget=256).generate(ps, copy.deepcopy(sp))
+    eng = gpu_engine(model, budget=256, kv_layer_groups=groups)
+    assert isinstance(eng.runner.pool, ops.LayerGroupedPool) and len(eng.runner.pool.groups) == groups
+    assert eng.generate(ps, copy.deepcopy(sp)) == want
+    assert eng.runner.step_kinds["decode_graph"] > 0

@@ -48,6 +48,9 @@ def build_parser() -> argparse.ArgumentParser:
     s.add_argument("--num-scheduler-steps", "--num_scheduler_steps", type=int, default=1,
                    help="decode steps launched back to back before the host reads the sampled tokens "
                         "(greedy decode-only batches with nothing waiting; tokens then arrive in groups)")
+    s.add_argument("--kv-layer-groups", "--kv_layer_groups", type=int, default=0,
+                   help="allocate the KV pool as this many pools of consecutive layers (faster decode reads "
+                        "on large pools); 0 = choose: 4 for a large GPU pool without KV tiers or transfers, else 1")
     s.add_argument("--distributed-executor-backend", default=None)
     _bool_pair(s, "enable-prefix-caching", True, "hash-chained prefix cache over KV pages")
     _bool_pair(s, "enable-chunked-prefill", True, "split long prompts across steps")
@@ -89,6 +92,7 @@ def config_from_args(args: argparse.Namespace) -> EngineConfig:
         pipeline_parallel_size=args.pipeline_parallel_size,
         enable_expert_parallel=args.enable_expert_parallel,
         num_scheduler_steps=max(1, args.num_scheduler_steps),
+        kv_layer_groups=max(0, args.kv_layer_groups),
         distributed_executor_backend=args.distributed_executor_backend,
         enable_lora=args.enable_lora, max_loras=args.max_loras, max_lora_rank=args.max_lora_rank,
         enable_sleep_mode=args.enable_sleep_mode,

@@ -365,6 +365,10 @@ class EngineConfig:
     # decode steps launched back to back before the host looks at the sampled tokens (greedy
     # decode-only batches of a single-rank replica with nothing waiting; 1 = every step)
     num_scheduler_steps: int = 1
+    # KV pool allocated as this many pools of consecutive layers (a decode step of one layer then
+    # walks a shorter address range); 0 = 4 for a large GPU pool whose pages never leave it whole
+    # (no lower KV tiers, no transfer between replicas), else 1
+    kv_layer_groups: int = 0
     distributed_executor_backend: str | None = None
     enable_lora: bool = False
     max_loras: int = 1

@@ -136,8 +136,35 @@ class ModelRunner:
         return (self.device.type == "cuda" and kt is not None and kt.kv_role in ("kv_consumer", "kv_both")
                 and os.environ.get("VPSA_PD_EXPORT_POOL", "1") != "0" and get_replica().size == 1)
 
-    def _alloc_pool(self) -> torch.Tensor:
+    # a pool below this size lies within the reach of address translation whatever its layout
+    LAYER_GROUPS_FROM_BYTES = 48 << 30
+
+    def _layer_groups(self) -> int:
+        """In how many layer groups the KV pool is allocated (``ops.LayerGroupedPool``).  1 = whole
+        pages, which every path that moves pages out of the pool needs (lower KV tiers, transfer
+        between replicas, the KV controller).  The default of 0 picks 4 for a GPU pool large enough
+        to gain from it when nothing of that kind is configured."""
+        g = int(self.cfg.kv_layer_groups)
+        off, kvt = self.cfg.kv_offload, self.cfg.kv_transfer
+        whole_pages = (off.enabled or off.enable_pd or off.enable_controller
+                       or kvt is not None) and not self.distributed
+        if g == 0:
+            g = 4 if (self.device.type == "cuda" and not whole_pages
+                      and self.num_pages * self.page_bytes >= self.LAYER_GROUPS_FROM_BYTES) else 1
+        if g > 1 and whole_pages:
+            log.warning("--kv-layer-groups %d ignored: KV tiers and transfers move whole pages", g)
+            g = 1
+        while g > 1 and self.n_layers_local % g:
+            g -= 1
+        return max(1, g)
+
+    def _alloc_pool(self):
         shape = (self.num_pages, self.n_layers_local, 2, self.n_kv_local, PAGE * self.kv_head_dim)
+        g = self._layer_groups()
+        if g > 1:
+            return ops.LayerGroupedPool([
+                torch.zeros((shape[0], shape[1] // g, *shape[2:]), dtype=self.dtype, device=self.device)
+                for _ in range(g)])
         if self._exports_pool():
             try:
                 return self._alloc_exported_pool()
@@ -442,7 +469,7 @@ class ModelRunner:
         self._sleep_stash = []
         # shrink the storages themselves: the transfer receiver, the tier connector and the
         # attention layers hold views of the pool, and a view must not keep 200 GiB resident
-        stores = [self.pool] if self.pool is not None else []
+        stores = list(getattr(self.pool, "groups", [self.pool])) if self.pool is not None else []
         if self.model is not None and hasattr(self.model, "weight_tensors"):
             stores += list(self.model.weight_tensors())
         if self.model is not None and hasattr(self.model, "packed_tensors"):

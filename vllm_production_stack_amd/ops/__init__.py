@@ -168,10 +168,54 @@ def kv_head_dim(head_dim: int, device) -> int:
 _pad_cos_sin: dict = {}
 
 
+class LayerGroupedPool:
+    """A paged KV pool cut by layer: ``groups[g]`` is a pool of its own,
+    ``[pages][layers / G][K|V][kv_head][64 x d]``, for layers ``g * per`` to ``(g + 1) * per - 1``
+    of every page; page ids are shared.  A decode step of one layer then walks an address range
+    G times shorter than with all layers in one page: on an MI355X the K/V read rate of the decode
+    kernel falls from 6.7 to 6.2-6.4 TB/s once the pages a step touches lie more than about 60 GB
+    apart (address translation), which a 250 GB pool of 8 MiB pages always is.  The price: a page
+    is G pieces, so only replicas whose pages never leave the pool as a whole (no lower tiers, no
+    transfer to another replica) use it."""
+
+    def __init__(self, groups):
+        self.groups = list(groups)
+        self.per = self.groups[0].shape[1]
+        assert all(g.shape == self.groups[0].shape and g.is_contiguous() for g in self.groups)
+
+    def for_layer(self, layer: int):
+        return self.groups[layer // self.per], layer % self.per
+
+    @property
+    def shape(self):  # the pool as a whole: [pages][layers][K|V][kv_head][64 x d]
+        s = self.groups[0].shape
+        return torch.Size((s[0], self.per * len(self.groups), *s[2:]))
+
+    dtype = property(lambda self: self.groups[0].dtype)
+    device = property(lambda self: self.groups[0].device)
+    is_cuda = property(lambda self: self.groups[0].is_cuda)
+
+    def numel(self) -> int:
+        return sum(g.numel() for g in self.groups)
+
+    def element_size(self) -> int:
+        return self.groups[0].element_size()
+
+    def page(self, p: int) -> torch.Tensor:
+        """A copy of page ``p`` as one tensor [layers][K|V][kv_head][64 x d]."""
+        return torch.cat([g[p] for g in self.groups], dim=0)
+
+    def write_page(self, p: int, page: torch.Tensor) -> None:
+        for i, g in enumerate(self.groups):
+            g[p].copy_(page[i * self.per:(i + 1) * self.per])
+
+
 def attention_block(qkv, pool, layer, meta, n_q, n_kv, head_dim, scale, cos_sin, rotary=True):
     """Rotary embedding, KV-cache write and paged attention of one layer for a mixed batch
     (``meta.num_decode`` decode rows first, then the prefill rows).  qkv [T, (n_q + 2 n_kv) * d];
     returns the attention output [T, n_q * d]."""
+    if isinstance(pool, LayerGroupedPool):
+        pool, layer = pool.for_layer(layer)
     t = qkv.shape[0]
     d = head_dim
     dk = kv_head_dim(d, qkv.device)

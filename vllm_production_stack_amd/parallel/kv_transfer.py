@@ -607,6 +607,9 @@ class KVReceiver:
         this host with a GPU gets landing-window slots, as many pages as there are free slots."""
         bm = self.engine.bm
         pool = self.engine.runner.pool
+        if not isinstance(pool, torch.Tensor):
+            raise ValueError("this replica keeps its KV pool in layer groups and cannot take whole pages: "
+                             "start it with its --kv-transfer-config (or --kv-layer-groups 1)")
         mine = pool.stride(0) * pool.element_size()
         if page_bytes != mine:
             raise ValueError(f"page size mismatch: sender {page_bytes}, receiver {mine}")
