@@ -662,13 +662,15 @@ def _skinny_ok(x, w, bias):
 #   o-proj  4096x4096   1-16 rows: 14.9-15.0 /  9.6-11.4 / 11.1-14.4   -> register-direct
 #   qkv     6144x4096   1-16 rows: 14.2      / 14.0-19.2 / 12.8-14.0   -> streaming
 #   gate_up 28672x4096  1-16 rows: 60.8-61.9 (+ activation) / 55.7-63 / 41.3-45.2; 24-32 rows:
-#                                  55 / - / 48.5-49.3                    -> streaming up to 32 rows
+#                                  55 / - / 48.5-49.3; 40 rows: 53.5-55.4 / - / 52.7; 48 rows (where
+#                                  the library's pick is a poor one): 63-65 / - / 53.7; 64 rows:
+#                                  54.7 / - / 58.5                       -> streaming up to 48 rows
 #   lm_head 128256x4096 1-16 rows: 187-189   / 209-288   / 173-184     -> streaming
 #   down    4096x14336: the library wins at every batch (24.8 vs 25.6)  -> library
-# From ~24 rows on (40 rows: qkv 17 vs 20, gate_up 53 vs 52) the library GEMM is as good or better.
+# From ~24 rows on (40 rows: qkv 17 vs 21, o 13 vs 18, down 36 vs 37) the library GEMM is as good or better.
 SMALL_BATCH_ROWS = 16
 PACKED_MAX_ROWS = 64
-PAIR_STREAM_MAX_ROWS = 32
+PAIR_STREAM_MAX_ROWS = 48
 DIRECT_MAX_WEIGHT_ELEMS = 4096 * 4096
 STREAM_MAX_K = 8192
 
