@@ -23,12 +23,14 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* __restrict
   const uint16_t* xr = x + (long)row * x_stride;
   uint16_t* rr = residual ? residual + (long)row * hidden : nullptr;
   float v[CHUNKS][8];
+  u32x4 ww[CHUNKS];  // fetched with the row: a load issued after the reduction would add its latency
   float ss = 0.f;
 #pragma unroll
   for (int c = 0; c < CHUNKS; ++c) {
     const int i = (c * 256 + tid) * 8;
     if (i < hidden) {
       u32x4 a = *reinterpret_cast<const u32x4*>(xr + i);
+      ww[c] = *reinterpret_cast<const u32x4*>(w + i);
       float t[8] = {bf16lo(a[0]), bf16hi(a[0]), bf16lo(a[1]), bf16hi(a[1]),
                     bf16lo(a[2]), bf16hi(a[2]), bf16lo(a[3]), bf16hi(a[3])};
       if (rr) {
@@ -69,11 +71,10 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* __restrict
   for (int c = 0; c < CHUNKS; ++c) {
     const int i = (c * 256 + tid) * 8;
     if (i < hidden) {
-      u32x4 ww = *reinterpret_cast<const u32x4*>(w + i);
       u32x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        o[k] = pack_bf16x2(v[c][2 * k] * inv * bf16lo(ww[k]), v[c][2 * k + 1] * inv * bf16hi(ww[k]));
+        o[k] = pack_bf16x2(v[c][2 * k] * inv * bf16lo(ww[c][k]), v[c][2 * k + 1] * inv * bf16hi(ww[c][k]));
       }
       *reinterpret_cast<u32x4*>(yr + i) = o;
     }
