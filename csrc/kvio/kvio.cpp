@@ -198,6 +198,27 @@ API int kvio_load_pages(void* h, void* dev_base, size_t page_bytes, const int64_
   return 0;
 }
 
+// One piece of every page: `part_bytes` at `dev_base + page * dev_stride` <-> the same number of
+// bytes at `slot_off` inside the page's pinned slot (a KV pool allocated as several pools of
+// consecutive layers keeps a page as one such piece per pool).  to_host: 1 = offload, 0 = load.
+API int kvio_copy_page_parts(void* h, void* dev_base, size_t dev_stride, size_t part_bytes, size_t slot_off,
+                             const int64_t* page_ids, const int64_t* slots, int n, int to_host,
+                             void* wait_event, void* done_event) {
+  bind_thread();
+  Pool* p = static_cast<Pool*>(h);
+  if (slot_off + part_bytes > p->slot_bytes || part_bytes > dev_stride) return -1;
+  if (wait_event && hipStreamWaitEvent(p->stream, (hipEvent_t)wait_event, 0) != hipSuccess) return -2;
+  for (int i = 0; i < n; ++i) {
+    char* dev = (char*)dev_base + (size_t)page_ids[i] * dev_stride;
+    char* host = p->slot_addr(slots[i]) + slot_off;
+    const hipError_t e = to_host ? hipMemcpyAsync(host, dev, part_bytes, hipMemcpyDeviceToHost, p->stream)
+                                 : hipMemcpyAsync(dev, host, part_bytes, hipMemcpyHostToDevice, p->stream);
+    if (e != hipSuccess) return -3;
+  }
+  if (done_event && hipEventRecord((hipEvent_t)done_event, p->stream) != hipSuccess) return -4;
+  return 0;
+}
+
 // ---------------------------------------------------------------- entropy coder (host)
 // The coder itself is host-only code in rangecoder.hpp (built and fuzzed under sanitizers by the
 // CPU test suite); these are its C entry points.

@@ -320,8 +320,6 @@ def test_a_pool_cut_into_layer_groups_generates_the_same_tokens():
     """``kv_layer_groups``: each group of layers keeps its K/V in a pool of its own; what attention
     reads and writes is the same, and replicas whose pages leave the pool as a whole keep one pool."""
     from vllm_production_stack_amd import ops
-    from vllm_production_stack_amd.engine.config import KVOffloadConfig
-
     g = torch.Generator().manual_seed(5)
     ps = [torch.randint(16, 500, (n,), generator=g).tolist() for n in (150, 70, 300)]
     ps.append(ps[0][:128] + ps[1][:40])  # shares two pages with the first prompt
@@ -336,9 +334,10 @@ def test_a_pool_cut_into_layer_groups_generates_the_same_tokens():
     assert page.shape == pool.shape[1:] and page.abs().sum() > 0
     pool.write_page(5, page)
     assert torch.equal(pool.page(5), page)
-    # a host tier moves whole pages: the request is ignored there
     assert isinstance(make_engine("tiny-llama-gqa", kv_layer_groups=2).runner.pool, torch.Tensor)  # 3 layers
-    tiered = make_engine("tiny-llama-gqa", kv_layer_groups=3,
-                         kv_offload=KVOffloadConfig(local_cpu=True, max_local_cpu_gb=0.01))
-    assert isinstance(tiered.runner.pool, torch.Tensor)
-    tiered.shutdown()
+    # a replica that exchanges pages with other replicas keeps whole pages: the request is ignored there
+    from vllm_production_stack_amd.engine.config import KVTransferConfig
+
+    pd = make_engine("tiny-llama-gqa", kv_layer_groups=3, kv_transfer=KVTransferConfig(kv_role="kv_consumer"))
+    assert isinstance(pd.runner.pool, torch.Tensor)
+    pd.shutdown()

@@ -172,8 +172,11 @@ def test_prefix_cache_hit_on_gpu():
     assert r.num_cached_tokens == 384 and r.output_ids == first
 
 
-def test_host_offload_roundtrip_on_gpu():
-    eng = gpu_engine(pages=12, kv_offload=KVOffloadConfig(local_cpu=True, max_local_cpu_gb=0.25))
+@pytest.mark.parametrize("groups", [1, 3])
+def test_host_offload_roundtrip_on_gpu(groups):
+    eng = gpu_engine(pages=12, kv_offload=KVOffloadConfig(local_cpu=True, max_local_cpu_gb=0.25),
+                     kv_layer_groups=groups)
+    assert len(getattr(eng.runner.pool, "groups", [0])) == groups
     a, b, c = prompts(3, 330, seed=5)
     first = eng.generate([a], copy.deepcopy(SP))[0]
     eng.generate([b], copy.deepcopy(SP))
@@ -186,8 +189,9 @@ def test_host_offload_roundtrip_on_gpu():
     assert eng.connector.host.loads >= 3
 
 
-def test_disk_tier_on_gpu(tmp_path):
-    eng = gpu_engine(pages=12, kv_offload=KVOffloadConfig(
+@pytest.mark.parametrize("groups", [1, 3])
+def test_disk_tier_on_gpu(tmp_path, groups):
+    eng = gpu_engine(pages=12, kv_layer_groups=groups, kv_offload=KVOffloadConfig(
         local_cpu=True, max_local_cpu_gb=0.0000001, max_local_disk_gb=0.2, local_disk_path=str(tmp_path)))
     a, b = prompts(2, 330, seed=6)
     first = eng.generate([a], copy.deepcopy(SP))[0]
@@ -627,7 +631,7 @@ def test_random_load_keeps_page_accounting_sound(chunk):
             model="tiny-llama-gqa", device="cuda", dtype="bfloat16", max_model_len=1024, num_scheduler_steps=run,
             max_num_seqs=rng.choice((2, 4, 8)), max_num_batched_tokens=budget,
             num_gpu_blocks_override=pages, enable_chunked_prefill=chunked, enable_prefix_caching=prefix,
-            enforce_eager=eager, port=0,
+            enforce_eager=eager, port=0, kv_layer_groups=1 + 2 * (seed % 2),  # whole pages / a pool per layer
             kv_offload=KVOffloadConfig(local_cpu=True, max_local_cpu_gb=0.02) if host else KVOffloadConfig())
         eng = LLMEngine(cfg)
         script = [(a, p[: (pages - 3) * 64 - 16], m, ab) for a, p, m, ab in _script(rng)]

@@ -19,10 +19,22 @@ from vllm_production_stack_amd.kv.serde import PageSerde, rc_decode, rc_encode
 SP = SamplingParams(max_tokens=4, temperature=0, ignore_eos=True)
 
 
+LAYOUT = {"groups": 1}
+
+
+@pytest.fixture(autouse=True, params=[1, 2], ids=["whole-pages", "layer-groups"])
+def pool_layout(request):
+    """Every test here runs on a pool of whole pages and on one pool per layer (tiny-llama has two
+    layers): the lower tiers see the same flat page either way."""
+    LAYOUT["groups"] = request.param
+    yield
+    LAYOUT["groups"] = 1
+
+
 def engine(pages=24, **off):
     cfg = EngineConfig(model="tiny-llama", device="cpu", dtype="float32", max_model_len=1024,
                        max_num_seqs=8, max_num_batched_tokens=256, num_gpu_blocks_override=pages,
-                       kv_offload=KVOffloadConfig(**off), port=0)
+                       kv_offload=KVOffloadConfig(**off), kv_layer_groups=LAYOUT["groups"], port=0)
     return LLMEngine(cfg)
 
 
@@ -207,7 +219,7 @@ def test_remote_page_evicted_between_store_and_reload_is_a_cache_miss():
     them back.  That is a cache miss (recompute from the first missing page), not an error, and
     the HBM pages reserved for the load are given back."""
     probe = engine()
-    page_bytes = probe.runner.pool[0].numel() * probe.runner.pool.element_size()
+    page_bytes = probe.runner.page_bytes
     probe.shutdown()
     # room for about two pages: every further upload evicts the oldest one
     loop, srv = _serve_in_thread(lambda: CacheServer("127.0.0.1", 0, int(2.5 * page_bytes)).start())

@@ -105,7 +105,8 @@ def test_random_interleavings_match_solo_generation(chunk):
             model="tiny-llama", device="cpu", dtype="float32", max_model_len=1024,
             max_num_seqs=rng.choice((2, 4, 8)), max_num_batched_tokens=budget,
             num_gpu_blocks_override=pages, enable_chunked_prefill=chunked, enable_prefix_caching=prefix,
-            kv_offload=KVOffloadConfig(local_cpu=True, max_local_cpu_gb=0.004) if host else KVOffloadConfig(), port=0)
+            kv_offload=KVOffloadConfig(local_cpu=True, max_local_cpu_gb=0.004) if host else KVOffloadConfig(), port=0,
+            kv_layer_groups=1 + seed % 2)  # whole pages / one pool per layer
         eng = LLMEngine(cfg)
         late = host and rng.random() < 0.7
         if late:

@@ -366,8 +366,9 @@ class EngineConfig:
     # decode-only batches of a single-rank replica with nothing waiting; 1 = every step)
     num_scheduler_steps: int = 1
     # KV pool allocated as this many pools of consecutive layers (a decode step of one layer then
-    # walks a shorter address range); 0 = 4 for a large GPU pool whose pages never leave it whole
-    # (no lower KV tiers, no transfer between replicas), else 1
+    # walks a shorter address range); 0 = 4 for a large GPU pool on a replica without lower KV tiers
+    # and without page transfers to or from other replicas, else 1.  Lower tiers work with any value
+    # (their copies are then per piece); replicas that exchange pages always keep whole pages.
     kv_layer_groups: int = 0
     distributed_executor_backend: str | None = None
     enable_lora: bool = False

@@ -141,18 +141,22 @@ class ModelRunner:
 
     def _layer_groups(self) -> int:
         """In how many layer groups the KV pool is allocated (``ops.LayerGroupedPool``).  1 = whole
-        pages, which every path that moves pages out of the pool needs (lower KV tiers, transfer
-        between replicas, the KV controller).  The default of 0 picks 4 for a GPU pool large enough
-        to gain from it when nothing of that kind is configured."""
+        pages, which the transfer of pages between replicas needs (a peer writes whole pages into
+        this pool, or reads them from it, in one copy each); the lower tiers (host memory, disk,
+        remote server) move a page piece by piece, which costs them: with every follow-up turn
+        reloaded from pinned host memory (prefix caching off), four 2 MiB copies per page instead
+        of one of 8 MiB took the reload-bound benchmark phase from 450 to 432 output tok/s.  So
+        the default of 0 picks 4 only for a large GPU pool on a replica without lower tiers and
+        outside such transfers; with tiers it is the operator's call (few reloads: take it)."""
         g = int(self.cfg.kv_layer_groups)
         off, kvt = self.cfg.kv_offload, self.cfg.kv_transfer
-        whole_pages = (off.enabled or off.enable_pd or off.enable_controller
-                       or kvt is not None) and not self.distributed
+        whole_pages = (off.enable_pd or kvt is not None) and not self.distributed
         if g == 0:
-            g = 4 if (self.device.type == "cuda" and not whole_pages
+            tiers = (off.enabled or off.enable_controller) and not self.distributed
+            g = 4 if (self.device.type == "cuda" and not whole_pages and not tiers
                       and self.num_pages * self.page_bytes >= self.LAYER_GROUPS_FROM_BYTES) else 1
         if g > 1 and whole_pages:
-            log.warning("--kv-layer-groups %d ignored: KV tiers and transfers move whole pages", g)
+            log.warning("--kv-layer-groups %d ignored: transfers between replicas move whole pages", g)
             g = 1
         while g > 1 and self.n_layers_local % g:
             g -= 1

@@ -29,6 +29,7 @@ import urllib.request
 
 import torch
 
+from .. import ops
 from ..engine.block_manager import PAGE
 from .remote import RemoteKVClient
 from .serde import PageSerde
@@ -86,7 +87,7 @@ class KVConnector:
         self._pool_exec = None  # worker threads of the codec path, created on first use
         self._inflight: set[int] = set()  # hashes whose upload has been queued but not finished
         if (self.remote is not None and self.pool.is_cuda and self.serde.kind == 0
-                and self.pool[0].numel() == self.serde.page_elems):
+                and ops.page_numel(self.pool) == self.serde.page_elems):
             n_stage = 128  # 1 GiB of pinned memory at 8 MiB per page
             self._stage = torch.empty((n_stage, self.serde.page_elems), dtype=self.pool.dtype, pin_memory=True)
             self._stage_free: queue.Queue = queue.Queue()
@@ -286,7 +287,7 @@ class KVConnector:
                 bad(h, "not found")
                 continue
             self.loaded_from[src] += 1
-            self.pool[p].view(-1).copy_(t.view(-1))
+            ops.page_assign(self.pool, p, t.view(-1))
             bulk_done.append((h, p))
         # Only pages in front of the first missing one stay with the request: the scheduler frees
         # the others at once and may hand them to somebody else while a copy to the host tier is
@@ -327,7 +328,7 @@ class KVConnector:
                 if h in self.remote_known:
                     continue
                 self.remote_known.add(h)
-                page = self.pool[p]
+                page = ops.page_tensor(self.pool, p)
                 if self.serde.uses_codec(page):
                     # quantise on the GPU here; the range coder (tens of ms per page) and the
                     # upload run on the worker pool
@@ -339,7 +340,7 @@ class KVConnector:
                     self._bg.put(lambda k=self._key(h), b=blob: self.remote.put(k, b))
         elif self.disk is not None and self.host is None:
             for h, p in fresh:
-                self.disk.put(h, self.pool[p].cpu())
+                self.disk.put(h, ops.page_tensor(self.pool, p).cpu())
         if self.controller_url:
             self._report({"instance_id": self.instance_id, "admit": [h for h, _ in fresh],
                           "url": self._self_url(), "ip": self._self_ip(),
@@ -382,9 +383,9 @@ class KVConnector:
                 left.append((h, p))
             elif got[0] == "raw":
                 t = torch.from_numpy(got[1]).view(self.pool.dtype)
-                self.pool[p].view(-1).copy_(t.to(self.device))
+                ops.page_assign(self.pool, p, t.to(self.device))
             else:
-                self.pool[p].view(-1).copy_(self.serde.restore(got, self.device).view(-1))
+                ops.page_assign(self.pool, p, self.serde.restore(got, self.device).view(-1))
         return left
 
     def _upload_staged(self, todo: list[tuple[int, int]]) -> None:
@@ -404,7 +405,7 @@ class KVConnector:
         st.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(st):
             for _h, p, slot in taken:
-                self._stage[slot].copy_(self.pool[p].reshape(-1), non_blocking=True)
+                ops.page_read_into(self.pool, p, self._stage[slot], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(st)
         pages = [p for _, p, _ in taken]
@@ -461,7 +462,7 @@ class KVConnector:
                     slot = None
                     left.append((h, p))
                     continue
-                self.pool[p].view(-1).copy_(self._stage[slot], non_blocking=True)
+                ops.page_assign(self.pool, p, self._stage[slot], non_blocking=True)
                 used.append(slot)
                 slot = None
         finally:

@@ -16,6 +16,7 @@ from ctypes import c_int, c_int64, c_size_t, c_void_p
 
 import torch
 
+from .. import ops
 from .serde import kvio
 
 log = logging.getLogger("vpsa.kv")
@@ -46,7 +47,7 @@ class _Event:
 class HostKVPool:
     def __init__(self, pool: torch.Tensor, capacity_bytes: int, on_spill=None):
         self.pool = pool
-        self.page_bytes = pool.stride(0) * pool.element_size()
+        self.page_bytes = ops.page_numel(pool) * pool.element_size()
         self.n_slots = max(1, int(capacity_bytes // self.page_bytes))
         self.index: OrderedDict[int, int] = OrderedDict()  # hash -> slot (LRU first)
         self.on_spill = on_spill
@@ -67,9 +68,9 @@ class HostKVPool:
             lib.kvio_event_query.argtypes = [c_void_p]
             lib.kvio_event_sync.argtypes = [c_void_p]
             lib.kvio_stream_wait_event.argtypes = [c_void_p, c_void_p]
-            for fn in (lib.kvio_offload_pages, lib.kvio_load_pages):
-                fn.restype = c_int
-                fn.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+            lib.kvio_copy_page_parts.restype = c_int
+            lib.kvio_copy_page_parts.argtypes = [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p,
+                                                 c_void_p, c_int, c_int, c_void_p, c_void_p]
             self.lib = lib
             self.h = c_void_p(lib.kvio_pool_create(pool.device.index or 0, self.page_bytes, self.n_slots))
             if not self.h:
@@ -148,15 +149,11 @@ class HostKVPool:
             slots = [self._slot_for(h) for h, _ in batch]
             if not self.gpu:
                 for (h, p), s in zip(batch, slots):
-                    self.host[s].copy_(self.pool[p])
+                    ops.page_read_into(self.pool, p, self.host[s].view(-1))
                 continue
             pages = (c_int64 * n)(*[p for _, p in batch])
             sl = (c_int64 * n)(*slots)
-            done = _Event(self.lib)
-            rc = self.lib.kvio_offload_pages(self.h, c_void_p(self.pool.data_ptr()), self.page_bytes,
-                                             pages, sl, n, wait.h if wait else None, done.h)
-            if rc != 0:
-                raise RuntimeError(f"kvio_offload_pages failed ({rc})")
+            done = self._copy_parts(pages, sl, n, True, wait)
         if done is not None:
             done._keep = wait
         return done
@@ -170,20 +167,32 @@ class HostKVPool:
         self.loads += len(items)
         if not self.gpu:
             for (h, p), s in zip(items, slots):
-                self.pool[p].copy_(self.host[s])
+                ops.page_assign(self.pool, p, self.host[s].view(-1))
             return None
         n = len(items)
         pages = (c_int64 * n)(*[p for _, p in items])
         sl = (c_int64 * n)(*slots)
-        done = _Event(self.lib)
         # the target pages may still be read by kernels already queued on the compute stream
         wait = _Event(self.lib)
         self.lib.kvio_event_record(wait.h, c_void_p(torch.cuda.current_stream(self.pool.device).cuda_stream))
-        rc = self.lib.kvio_load_pages(self.h, c_void_p(self.pool.data_ptr()), self.page_bytes, pages,
-                                      sl, n, wait.h, done.h)
-        if rc != 0:
-            raise RuntimeError(f"kvio_load_pages failed ({rc})")
+        done = self._copy_parts(pages, sl, n, False, wait)
         done._keep = wait
+        return done
+
+    def _copy_parts(self, pages, slots, n: int, to_host: bool, wait):
+        """Queue the copies of ``n`` pages on the copy stream, one piece per pool the KV pool is made
+        of, behind ``wait``; returns the event recorded after the last one."""
+        done = _Event(self.lib)
+        parts = ops.page_parts(self.pool, 0)
+        off = 0
+        for i, part in enumerate(parts):
+            nbytes = part.numel() * part.element_size()
+            rc = self.lib.kvio_copy_page_parts(
+                self.h, c_void_p(part.data_ptr()), nbytes, nbytes, off, pages, slots, n, 1 if to_host else 0,
+                wait.h if (wait is not None and i == 0) else None, done.h if i == len(parts) - 1 else None)
+            if rc != 0:
+                raise RuntimeError(f"kvio_copy_page_parts failed ({rc})")
+            off += nbytes
         return done
 
     def make_compute_wait(self, ev) -> None:

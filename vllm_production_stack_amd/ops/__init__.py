@@ -175,8 +175,8 @@ class LayerGroupedPool:
     G times shorter than with all layers in one page: on an MI355X the K/V read rate of the decode
     kernel falls from 6.7 to 6.2-6.4 TB/s once the pages a step touches lie more than about 60 GB
     apart (address translation), which a 250 GB pool of 8 MiB pages always is.  The price: a page
-    is G pieces, so only replicas whose pages never leave the pool as a whole (no lower tiers, no
-    transfer to another replica) use it."""
+    is G pieces; the lower tiers copy it piece by piece (``page_parts``), replicas that push pages
+    to or take pages from other replicas keep whole pages."""
 
     def __init__(self, groups):
         self.groups = list(groups)
@@ -208,6 +208,45 @@ class LayerGroupedPool:
     def write_page(self, p: int, page: torch.Tensor) -> None:
         for i, g in enumerate(self.groups):
             g[p].copy_(page[i * self.per:(i + 1) * self.per])
+
+
+# A page as the lower KV tiers see it is the flat [layers][K|V][kv_head][64 x d] array whatever
+# the pool's layout: the pieces of a grouped pool, in group order, are exactly that array.
+def page_parts(pool, p: int) -> list:
+    """The contiguous device pieces of page ``p``, in layer order."""
+    if isinstance(pool, LayerGroupedPool):
+        return [g[p] for g in pool.groups]
+    return [pool[p]]
+
+
+def page_numel(pool) -> int:
+    n = 1
+    for d in pool.shape[1:]:
+        n *= int(d)
+    return n
+
+
+def page_tensor(pool, p: int) -> torch.Tensor:
+    """Page ``p`` as [layers][K|V][kv_head][64 x d]: a view of a whole-page pool, a copy of a grouped one."""
+    return pool.page(p) if isinstance(pool, LayerGroupedPool) else pool[p]
+
+
+def page_read_into(pool, p: int, flat: torch.Tensor, non_blocking: bool = False) -> None:
+    """``flat`` (page_numel elements, any device) <- page ``p``."""
+    off = 0
+    for part in page_parts(pool, p):
+        n = part.numel()
+        flat[off:off + n].copy_(part.reshape(-1), non_blocking=non_blocking)
+        off += n
+
+
+def page_assign(pool, p: int, flat: torch.Tensor, non_blocking: bool = False) -> None:
+    """Page ``p`` <- ``flat`` (page_numel elements, any device)."""
+    off = 0
+    for part in page_parts(pool, p):
+        n = part.numel()
+        part.view(-1).copy_(flat[off:off + n], non_blocking=non_blocking)
+        off += n
 
 
 def attention_block(qkv, pool, layer, meta, n_q, n_kv, head_dim, scale, cos_sin, rotary=True):
