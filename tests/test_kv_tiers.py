@@ -167,6 +167,24 @@ def test_disk_tier_after_host_eviction(tmp_path):
     assert len(list(tmp_path.rglob("*.kv"))) > 0  # under the model-identity directory
 
 
+def test_pages_on_disk_are_the_same_for_both_pool_layouts(tmp_path):
+    """A replica with one pool per layer writes its pages to disk; a replica with whole pages (and
+    the other way round) finds them there and continues with the same tokens."""
+    mine = LAYOUT["groups"]
+    a = prompts(1, 330, seed=9)[0]
+    writer = engine(pages=12, max_local_disk_gb=0.1, local_disk_path=str(tmp_path))
+    first = writer.generate([a], copy.deepcopy(SP))[0]
+    assert len(getattr(writer.runner.pool, "groups", [0])) == mine
+    writer.shutdown()
+    LAYOUT["groups"] = 3 - mine
+    reader = engine(pages=12, max_local_disk_gb=0.1, local_disk_path=str(tmp_path))
+    assert len(getattr(reader.runner.pool, "groups", [0])) == 3 - mine
+    r = reader.add_request(a, copy.deepcopy(SP))
+    while reader.has_work():
+        reader.step()
+    assert r.num_external_tokens == 320 and r.output_ids == first
+
+
 def _serve_in_thread(coro_factory):
     loop = asyncio.new_event_loop()
     box = {}
