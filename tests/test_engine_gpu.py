@@ -204,14 +204,17 @@ def test_disk_tier_on_gpu(tmp_path, groups):
     assert r.output_ids == first
 
 
-def test_sleep_and_wake_keep_serving():
-    eng = gpu_engine(enable_sleep_mode=True)
+@pytest.mark.parametrize("groups", [1, 3])
+def test_sleep_and_wake_keep_serving(groups):
+    eng = gpu_engine(enable_sleep_mode=True, kv_layer_groups=groups)
+    assert len(getattr(eng.runner.pool, "groups", [0])) == groups
     (p,) = prompts(1, 100, seed=8)
     first = eng.generate([p], copy.deepcopy(SP))[0]
     free_before = torch.cuda.mem_get_info()[0]
     eng.sleep(1)
     assert torch.cuda.mem_get_info()[0] > free_before
     eng.wake_up()
+    assert len(getattr(eng.runner.pool, "groups", [0])) == groups
     assert eng.generate([p], copy.deepcopy(SP))[0] == first
 
 
