@@ -23,15 +23,20 @@ from vllm_production_stack_amd.engine.request import SamplingParams  # noqa: E40
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kv-layer-groups", type=int, default=0)
+    ap.add_argument("--prompt-len", type=int, default=3000)
+    ap.add_argument("--repeats", type=int, default=1, help="plain repeats before the nap")
     a = ap.parse_args()
     eng = LLMEngine(EngineConfig(model="llama-3-8b", device="cuda", dtype="bfloat16", max_model_len=8192,
                                  max_num_seqs=8, enable_sleep_mode=True, kv_layer_groups=a.kv_layer_groups, port=0))
     g = torch.Generator().manual_seed(0)
-    ps = [torch.randint(16, 30000, (3000,), generator=g).tolist() for _ in range(2)]
+    ps = [torch.randint(16, 30000, (a.prompt_len,), generator=g).tolist() for _ in range(2)]
     sp = SamplingParams(max_tokens=16, temperature=0, ignore_eos=True)
     first = eng.generate(ps, copy.deepcopy(sp))
-    eng.bm.reset_prefix_cache()
-    repeat = eng.generate(ps, copy.deepcopy(sp))  # the same work without a nap in between
+    same = []
+    for _ in range(a.repeats):
+        eng.bm.reset_prefix_cache()
+        repeat = eng.generate(ps, copy.deepcopy(sp))  # the same work without a nap in between
+        same.append(repeat == first)
     free0 = torch.cuda.mem_get_info()[0]
     t0 = time.time()
     freed = eng.sleep(1)
@@ -43,7 +48,7 @@ def main():
     print(json.dumps({"kv_layer_groups": len(getattr(eng.runner.pool, "groups", [0])),
                       "pages": eng.runner.num_pages, "freed_GiB": round(freed / 2**30, 1),
                       "hbm_free_GiB_before_asleep": [round(free0 / 2**30, 1), round(free1 / 2**30, 1)],
-                      "sleep_s": round(t1 - t0, 2), "wake_s": round(t2 - t1, 2), "same_tokens_after_waking": again == first, "same_tokens_on_a_plain_repeat": repeat == first,
+                      "sleep_s": round(t1 - t0, 2), "wake_s": round(t2 - t1, 2), "same_tokens_after_waking": again == first, "same_tokens_on_a_plain_repeat": all(same), "repeats_same": same, "prompt_len": a.prompt_len,
                       "first": first[0][:8], "repeat": repeat[0][:8], "again": again[0][:8]}))
     assert all(len(o) == 16 for o in again)
 
